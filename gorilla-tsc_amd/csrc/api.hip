@@ -1,0 +1,445 @@
+// C ABI of the gtsc library (see include/gtsc.h).  Host code only: argument
+// checks, stream/scratch ownership, chunked host<->device staging.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/gtsc.h"
+#include "kernels.hpp"
+
+using namespace gtsc;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(GTSC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        size_t want = need + need / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, need); want = need; }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct gtsc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;   // the one launches go to
+    uint32_t* d_flags = nullptr;    // OR of status bits raised since the last sync
+    uint32_t* h_flags = nullptr;    // pinned mirror
+    DeviceBuf scan_scratch;
+    // staging for the host entry points, two sets for double buffering
+    struct Stage {
+        hipStream_t stream = nullptr;
+        DeviceBuf block_ts, ts, val, pt_off, slots, slot_off, nwords, coff, compact, status, npoints;
+    } stage[2];
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int check_ctx(gtsc_ctx* ctx)
+{
+    if (!ctx) return fail(GTSC_ERR_ARG, "ctx is NULL");
+    return GTSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtsc_version(void) { return 1000; }
+
+const char* gtsc_last_error(void) { return g_err; }
+
+uint64_t gtsc_max_words(uint64_t npoints)
+{
+    const uint64_t bits = 64 + (npoints ? 91 + 114 * (npoints - 1) : 0) + 37;
+    return bits / 64 + 2;
+}
+
+int gtsc_create(int device_id, gtsc_ctx** out)
+{
+    if (!out) return fail(GTSC_ERR_ARG, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(GTSC_ERR_HIP, "no HIP device available");
+    if (device_id < 0) HIP_TRY(hipGetDevice(&device_id));
+    if (device_id >= ndev) return fail(GTSC_ERR_ARG, "device %d out of range (%d devices)", device_id, ndev);
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GTSC_ERR_HIP, "cannot select device %d", device_id);
+    gtsc_ctx* c = new (std::nothrow) gtsc_ctx();
+    if (!c) return fail(GTSC_ERR_ARG, "out of host memory");
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        int rc = fail(GTSC_ERR_HIP, "context setup: %s", hipGetErrorString(e));
+        gtsc_destroy(c);
+        return rc;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return GTSC_OK;
+}
+
+int gtsc_destroy(gtsc_ctx* c)
+{
+    if (!c) return GTSC_OK;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->stage) {
+        if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+        for (DeviceBuf* b : {&s.block_ts, &s.ts, &s.val, &s.pt_off, &s.slots, &s.slot_off, &s.nwords, &s.coff,
+                             &s.compact, &s.status, &s.npoints})
+            b->release();
+    }
+    c->scan_scratch.release();
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return GTSC_OK;
+}
+
+int gtsc_set_stream(gtsc_ctx* c, void* hip_stream)
+{
+    if (int rc = check_ctx(c)) return rc;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return GTSC_OK;
+}
+
+int gtsc_sync(gtsc_ctx* c)
+{
+    if (int rc = check_ctx(c)) return rc;
+    DeviceGuard g(c->device);
+    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t f = *c->h_flags;
+    if (f & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", f);
+    if (f & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series overflowed their output slot");
+    return GTSC_OK;
+}
+
+int gtsc_encode_device(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* block_ts, const int64_t* ts,
+                       const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints, uint64_t* out_words,
+                       const uint64_t* out_off, uint64_t uniform_slot_words, uint64_t* out_nwords, uint32_t* status)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (format != GTSC_FMT_V2 && format != GTSC_FMT_V1) return fail(GTSC_ERR_ARG, "unknown format %d", format);
+    if (nseries == 0) return GTSC_OK;
+    if (!block_ts || !out_words || !out_nwords) return fail(GTSC_ERR_ARG, "block_ts/out_words/out_nwords must not be NULL");
+    if ((!ts || !val) && (pt_off || uniform_npoints)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    if (!out_off && uniform_slot_words < 3) return fail(GTSC_ERR_ARG, "uniform_slot_words must be at least 3 (an empty block)");
+    DeviceGuard g(c->device);
+    EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
+                 out_nwords, status, c->d_flags};
+    HIP_TRY(launch_encode(a, format, c->stream));
+    return GTSC_OK;
+}
+
+int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* words, const uint64_t* in_off,
+                       uint64_t uniform_slot_words, const uint64_t* in_nwords, int64_t* ts, uint64_t* val,
+                       const uint64_t* pt_off, uint64_t uniform_capacity, uint64_t* out_npoints, uint32_t* status)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (format != GTSC_FMT_V2 && format != GTSC_FMT_V1) return fail(GTSC_ERR_ARG, "unknown format %d", format);
+    if (nseries == 0) return GTSC_OK;
+    if (!words || !out_npoints) return fail(GTSC_ERR_ARG, "words/out_npoints must not be NULL");
+    if ((!ts || !val) && (pt_off || uniform_capacity)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    DeviceGuard g(c->device);
+    DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
+                 out_npoints, status, c->d_flags};
+    HIP_TRY(launch_decode(a, format, c->stream));
+    return GTSC_OK;
+}
+
+int gtsc_compact_device(gtsc_ctx* c, uint64_t nseries, const uint64_t* slot_words, const uint64_t* slot_off,
+                        uint64_t uniform_slot_words, const uint64_t* nwords, uint64_t* compact_words, uint64_t* compact_off)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!compact_off) return fail(GTSC_ERR_ARG, "compact_off must not be NULL");
+    if (nseries && (!slot_words || !nwords || !compact_words)) return fail(GTSC_ERR_ARG, "slot_words/nwords/compact_words must not be NULL");
+    DeviceGuard g(c->device);
+    HIP_TRY(c->scan_scratch.reserve(scan_scratch_words(nseries) * sizeof(uint64_t)));
+    HIP_TRY(launch_exclusive_scan(nwords, nseries, compact_off, c->scan_scratch.as<uint64_t>(), c->stream));
+    HIP_TRY(launch_compact_copy(nseries, slot_words, Layout{slot_off, uniform_slot_words}, nwords, compact_words,
+                                compact_off, c->stream));
+    return GTSC_OK;
+}
+
+
+// ------------------------------------------------------------------------
+// Host-memory entry points: chunked, two alternating streams.
+// ------------------------------------------------------------------------
+void* gtsc_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(GTSC_ERR_HIP, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void gtsc_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"
+
+namespace {
+
+constexpr uint64_t CHUNK_POINTS = 16ull << 20;  // 256 MiB of raw points per chunk
+constexpr uint64_t CHUNK_SERIES = 4ull << 20;
+
+struct Chunk { uint64_t s0, s1; };
+
+// cut [0, nseries) into runs of whole series of at most CHUNK_POINTS points
+std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t uniform)
+{
+    std::vector<Chunk> out;
+    uint64_t s = 0;
+    while (s < nseries) {
+        uint64_t e = s, pts = 0;
+        while (e < nseries && e - s < CHUNK_SERIES) {
+            const uint64_t n = off ? off[e + 1] - off[e] : uniform;
+            if (e > s && pts + n > CHUNK_POINTS) break;
+            pts += n;
+            e++;
+        }
+        out.push_back({s, e});
+        s = e;
+    }
+    return out;
+}
+
+int ensure_stage_streams(gtsc_ctx* c)
+{
+    for (auto& st : c->stage)
+        if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    return GTSC_OK;
+}
+
+int read_flags(gtsc_ctx* c, hipStream_t stream, uint32_t* out)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *out = *c->h_flags;
+    return GTSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* block_ts, const int64_t* ts,
+                     const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints, uint64_t* out_words,
+                     uint64_t out_capacity_words, uint64_t* out_off)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (format != GTSC_FMT_V2 && format != GTSC_FMT_V1) return fail(GTSC_ERR_ARG, "unknown format %d", format);
+    if (!out_off) return fail(GTSC_ERR_ARG, "out_off must not be NULL");
+    out_off[0] = 0;
+    if (nseries == 0) return GTSC_OK;
+    if (!block_ts || !out_words) return fail(GTSC_ERR_ARG, "block_ts/out_words must not be NULL");
+    if ((!ts || !val) && (pt_off || uniform_npoints)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    DeviceGuard g(c->device);
+    if (int rc = ensure_stage_streams(c)) return rc;
+
+    const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_npoints);
+    std::vector<uint64_t> rebased[2], slot_off[2];
+    struct Pending { bool live = false; uint64_t s0 = 0, s1 = 0; } pending[2];
+    uint64_t base = 0;      // words produced by the chunks completed so far
+    bool overflow = false;
+
+    // finish a chunk: learn its size, then start copying its packed words out
+    auto complete = [&](int b) -> int {
+        Pending& p = pending[b];
+        if (!p.live) return GTSC_OK;
+        auto& st = c->stage[b];
+        HIP_TRY(hipStreamSynchronize(st.stream));
+        const uint64_t ns = p.s1 - p.s0;
+        // out_off[s0+1 .. s1] hold chunk-local prefix sums; make them global
+        for (uint64_t i = 1; i <= ns; i++) out_off[p.s0 + i] += base;
+        const uint64_t total = out_off[p.s1] - base;
+        if (base + total > out_capacity_words) overflow = true;
+        else if (total)
+            HIP_TRY(hipMemcpyAsync(out_words + base, st.compact.p, total * sizeof(uint64_t), hipMemcpyDeviceToHost, st.stream));
+        base += total;
+        p.live = false;
+        return GTSC_OK;
+    };
+
+    for (size_t k = 0; k < chunks.size(); k++) {
+        const int b = (int)(k & 1);
+        if (int rc = complete(b)) return rc;  // the chunk that used this stage two steps ago
+        auto& st = c->stage[b];
+        HIP_TRY(hipStreamSynchronize(st.stream));  // its copy-out must be done before the buffers are reused
+        const uint64_t s0 = chunks[k].s0, s1 = chunks[k].s1, ns = s1 - s0;
+        const uint64_t p0 = pt_off ? pt_off[s0] : s0 * uniform_npoints;
+        const uint64_t np = (pt_off ? pt_off[s1] : s1 * uniform_npoints) - p0;
+        uint64_t slot_total, uniform_slot = 0;
+        const uint64_t* d_pt_off = nullptr;
+        const uint64_t* d_slot_off = nullptr;
+        if (pt_off) {
+            rebased[b].resize(ns + 1);
+            slot_off[b].resize(ns + 1);
+            slot_off[b][0] = 0;
+            for (uint64_t i = 0; i <= ns; i++) rebased[b][i] = pt_off[s0 + i] - p0;
+            for (uint64_t i = 0; i < ns; i++) slot_off[b][i + 1] = slot_off[b][i] + gtsc_max_words(rebased[b][i + 1] - rebased[b][i]);
+            slot_total = slot_off[b][ns];
+            HIP_TRY(st.pt_off.reserve((ns + 1) * 8));
+            HIP_TRY(st.slot_off.reserve((ns + 1) * 8));
+            HIP_TRY(hipMemcpyAsync(st.pt_off.p, rebased[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
+            HIP_TRY(hipMemcpyAsync(st.slot_off.p, slot_off[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
+            d_pt_off = st.pt_off.as<uint64_t>();
+            d_slot_off = st.slot_off.as<uint64_t>();
+        } else {
+            uniform_slot = gtsc_max_words(uniform_npoints);
+            slot_total = uniform_slot * ns;
+        }
+        HIP_TRY(st.block_ts.reserve(ns * 8));
+        HIP_TRY(st.ts.reserve(np * 8 + 8));
+        HIP_TRY(st.val.reserve(np * 8 + 8));
+        HIP_TRY(st.slots.reserve(slot_total * 8));
+        HIP_TRY(st.compact.reserve(slot_total * 8));
+        HIP_TRY(st.nwords.reserve(ns * 8));
+        HIP_TRY(st.coff.reserve((ns + 1) * 8));
+        HIP_TRY(c->scan_scratch.reserve(scan_scratch_words(CHUNK_SERIES) * 2 * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpyAsync(st.block_ts.p, block_ts + s0, ns * 8, hipMemcpyHostToDevice, st.stream));
+        if (np) {
+            HIP_TRY(hipMemcpyAsync(st.ts.p, ts + p0, np * 8, hipMemcpyHostToDevice, st.stream));
+            HIP_TRY(hipMemcpyAsync(st.val.p, val + p0, np * 8, hipMemcpyHostToDevice, st.stream));
+        }
+        EncodeArgs a{ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
+                     Layout{d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot},
+                     st.nwords.as<uint64_t>(), nullptr, c->d_flags};
+        HIP_TRY(launch_encode(a, format, st.stream));
+        uint64_t* scratch = c->scan_scratch.as<uint64_t>() + (size_t)b * scan_scratch_words(CHUNK_SERIES);
+        HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), ns, st.coff.as<uint64_t>(), scratch, st.stream));
+        HIP_TRY(launch_compact_copy(ns, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot}, st.nwords.as<uint64_t>(),
+                                    st.compact.as<uint64_t>(), st.coff.as<uint64_t>(), st.stream));
+        HIP_TRY(hipMemcpyAsync(out_off + s0 + 1, st.coff.as<uint64_t>() + 1, ns * 8, hipMemcpyDeviceToHost, st.stream));
+        pending[b] = {true, s0, s1};
+        // chunks complete in order: the other stage's chunk is older
+        if (int rc = complete(b ^ 1)) return rc;
+    }
+    // at most one chunk is still pending: the last one
+    if (int rc = complete((int)((chunks.size() - 1) & 1))) return rc;
+    for (auto& st : c->stage) HIP_TRY(hipStreamSynchronize(st.stream));
+    uint32_t flags = 0;
+    if (int rc = read_flags(c, c->stage[0].stream, &flags)) return rc;
+    if (overflow) return fail(GTSC_ERR_CAPACITY, "out_words holds %llu words, the batch needs %llu",
+                              (unsigned long long)out_capacity_words, (unsigned long long)out_off[nseries]);
+    if (flags) return fail(GTSC_ERR_HIP, "internal: worst-case slot overflowed (flags 0x%x)", flags);
+    return GTSC_OK;
+}
+
+int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* words, const uint64_t* in_off,
+                     int64_t* ts, uint64_t* val, const uint64_t* pt_off, uint64_t uniform_capacity,
+                     uint64_t* out_npoints, uint32_t* status)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (format != GTSC_FMT_V2 && format != GTSC_FMT_V1) return fail(GTSC_ERR_ARG, "unknown format %d", format);
+    if (nseries == 0) return GTSC_OK;
+    if (!words || !in_off || !out_npoints) return fail(GTSC_ERR_ARG, "words/in_off/out_npoints must not be NULL");
+    if ((!ts || !val) && (pt_off || uniform_capacity)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    DeviceGuard g(c->device);
+    if (int rc = ensure_stage_streams(c)) return rc;
+
+    const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_capacity);
+    std::vector<uint64_t> reb_in[2], reb_pt[2];
+    for (size_t k = 0; k < chunks.size(); k++) {
+        const int b = (int)(k & 1);
+        auto& st = c->stage[b];
+        HIP_TRY(hipStreamSynchronize(st.stream));
+        const uint64_t s0 = chunks[k].s0, s1 = chunks[k].s1, ns = s1 - s0;
+        const uint64_t w0 = in_off[s0], nw = in_off[s1] - w0;
+        const uint64_t p0 = pt_off ? pt_off[s0] : s0 * uniform_capacity;
+        const uint64_t np = (pt_off ? pt_off[s1] : s1 * uniform_capacity) - p0;
+        reb_in[b].resize(ns + 1);
+        for (uint64_t i = 0; i <= ns; i++) reb_in[b][i] = in_off[s0 + i] - w0;
+        HIP_TRY(st.slot_off.reserve((ns + 1) * 8));
+        HIP_TRY(hipMemcpyAsync(st.slot_off.p, reb_in[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
+        const uint64_t* d_pt_off = nullptr;
+        if (pt_off) {
+            reb_pt[b].resize(ns + 1);
+            for (uint64_t i = 0; i <= ns; i++) reb_pt[b][i] = pt_off[s0 + i] - p0;
+            HIP_TRY(st.pt_off.reserve((ns + 1) * 8));
+            HIP_TRY(hipMemcpyAsync(st.pt_off.p, reb_pt[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
+            d_pt_off = st.pt_off.as<uint64_t>();
+        }
+        HIP_TRY(st.compact.reserve(nw * 8 + 8));
+        HIP_TRY(st.ts.reserve(np * 8 + 8));
+        HIP_TRY(st.val.reserve(np * 8 + 8));
+        HIP_TRY(st.npoints.reserve(ns * 8));
+        HIP_TRY(st.status.reserve(ns * 4));
+        if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, st.stream));
+        DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
+                     st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
+                     st.status.as<uint32_t>(), c->d_flags};
+        HIP_TRY(launch_decode(a, format, st.stream));
+        if (np) {
+            HIP_TRY(hipMemcpyAsync(ts + p0, st.ts.p, np * 8, hipMemcpyDeviceToHost, st.stream));
+            HIP_TRY(hipMemcpyAsync(val + p0, st.val.p, np * 8, hipMemcpyDeviceToHost, st.stream));
+        }
+        HIP_TRY(hipMemcpyAsync(out_npoints + s0, st.npoints.p, ns * 8, hipMemcpyDeviceToHost, st.stream));
+        if (status) HIP_TRY(hipMemcpyAsync(status + s0, st.status.p, ns * 4, hipMemcpyDeviceToHost, st.stream));
+    }
+    for (auto& st : c->stage) HIP_TRY(hipStreamSynchronize(st.stream));
+    uint32_t flags = 0;
+    if (int rc = read_flags(c, c->stage[0].stream, &flags)) return rc;
+    if (flags & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", flags);
+    if (flags & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series hold more points than their ts/val slot");
+    return GTSC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// Kernel argument blocks and host-side launchers (internal to the library).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codec_device.hpp"
+
+namespace gtsc {
+
+struct EncodeArgs {
+    uint64_t nseries;
+    const int64_t* block_ts;
+    const int64_t* ts;
+    const uint64_t* val;
+    Layout pts;          // points of series s
+    uint64_t* out_words;
+    Layout slots;        // output slot of series s
+    uint64_t* out_nwords;
+    uint32_t* status;    // may be null
+    uint32_t* flags;     // one word: OR of all status bits raised
+};
+
+struct DecodeArgs {
+    uint64_t nseries;
+    const uint64_t* words;
+    Layout slots;             // image slot of series s
+    const uint64_t* in_nwords;  // may be null
+    int64_t* ts;
+    uint64_t* val;
+    Layout pts;               // capacity slot of series s
+    uint64_t* out_npoints;
+    uint32_t* status;         // may be null
+    uint32_t* flags;
+};
+
+hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);
+hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
+
+// out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); scratch holds
+// scan_scratch_words(n) words.
+uint64_t scan_scratch_words(uint64_t n);
+hipError_t launch_exclusive_scan(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* scratch, hipStream_t stream);
+hipError_t launch_compact_copy(uint64_t nseries, const uint64_t* slot_words, Layout slots, const uint64_t* nwords,
+                               uint64_t* dst, const uint64_t* dst_off, hipStream_t stream);
+
+}  // namespace gtsc

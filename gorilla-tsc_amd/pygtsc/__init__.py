@@ -1,0 +1,174 @@
+"""ctypes binding of libgtsc.so (the C ABI in include/gtsc.h).
+
+Thin by design: it loads the shared library, declares the prototypes, and
+offers a Context whose methods take either torch CUDA tensors (device entry
+points) or numpy arrays (host entry points).  There is no fallback of any
+kind: if the library or a GPU is missing, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgtsc.so")
+
+OK, ERR_ARG, ERR_CAPACITY, ERR_HIP, ERR_STREAM = 0, -1, -2, -3, -4
+FMT_V2, FMT_V1 = 0, 1
+ST_OVERFLOW, ST_TRUNCATED, ST_MALFORMED = 1, 2, 4
+
+# every symbol include/gtsc.h declares
+SYMBOLS = (
+    "gtsc_version", "gtsc_last_error", "gtsc_max_words", "gtsc_create", "gtsc_destroy", "gtsc_set_stream",
+    "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
+    "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free",
+)
+
+
+class GtscError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gtsc error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libgtsc.so (built in-tree by `make -C gorilla-tsc_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libgtsc.so not built: run `make -C %s`" % os.path.dirname(LIB_PATH))
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.gtsc_version.restype = i32
+    L.gtsc_last_error.restype = C.c_char_p
+    L.gtsc_max_words.restype = u64
+    L.gtsc_max_words.argtypes = [u64]
+    L.gtsc_create.restype = i32
+    L.gtsc_create.argtypes = [i32, C.POINTER(vp)]
+    L.gtsc_destroy.restype = i32
+    L.gtsc_destroy.argtypes = [vp]
+    L.gtsc_set_stream.restype = i32
+    L.gtsc_set_stream.argtypes = [vp, vp]
+    L.gtsc_sync.restype = i32
+    L.gtsc_sync.argtypes = [vp]
+    L.gtsc_encode_device.restype = i32
+    L.gtsc_encode_device.argtypes = [vp, i32, u64, vp, vp, vp, vp, u64, vp, vp, u64, vp, vp]
+    L.gtsc_decode_device.restype = i32
+    L.gtsc_decode_device.argtypes = [vp, i32, u64, vp, vp, u64, vp, vp, vp, vp, u64, vp, vp]
+    L.gtsc_compact_device.restype = i32
+    L.gtsc_compact_device.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp]
+    L.gtsc_encode_host.restype = i32
+    L.gtsc_encode_host.argtypes = [vp, i32, u64, vp, vp, vp, vp, u64, vp, u64, vp]
+    L.gtsc_decode_host.restype = i32
+    L.gtsc_decode_host.argtypes = [vp, i32, u64, vp, vp, vp, vp, vp, u64, vp, vp]
+    L.gtsc_host_alloc.restype = vp
+    L.gtsc_host_alloc.argtypes = [C.c_size_t]
+    L.gtsc_host_free.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def max_words(npoints):
+    return int(lib().gtsc_max_words(int(npoints)))
+
+
+def _check(rc):
+    if rc != OK:
+        raise GtscError(rc, lib().gtsc_last_error().decode())
+
+
+def _dp(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _hp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """gtsc_ctx owner.  Device methods enqueue on the context's stream; call sync()."""
+
+    def __init__(self, device=-1):
+        h = C.c_void_p()
+        _check(lib().gtsc_create(int(device), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gtsc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, hip_stream):
+        _check(lib().gtsc_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def sync(self):
+        _check(lib().gtsc_sync(self._h))
+
+    # ---- device-resident -------------------------------------------------
+    def encode_device(self, block_ts, ts, val, out_words, out_nwords, pt_off=None, uniform_npoints=0,
+                      out_off=None, uniform_slot_words=0, status=None, fmt=FMT_V2):
+        S = block_ts.numel()
+        _check(lib().gtsc_encode_device(self._h, fmt, S, _dp(block_ts), _dp(ts), _dp(val), _dp(pt_off),
+                                        int(uniform_npoints), _dp(out_words), _dp(out_off), int(uniform_slot_words),
+                                        _dp(out_nwords), _dp(status)))
+
+    def decode_device(self, words, ts, val, out_npoints, nseries, in_off=None, uniform_slot_words=0, in_nwords=None,
+                      pt_off=None, uniform_capacity=0, status=None, fmt=FMT_V2):
+        _check(lib().gtsc_decode_device(self._h, fmt, int(nseries), _dp(words), _dp(in_off), int(uniform_slot_words),
+                                        _dp(in_nwords), _dp(ts), _dp(val), _dp(pt_off), int(uniform_capacity),
+                                        _dp(out_npoints), _dp(status)))
+
+    def compact_device(self, slot_words, nwords, compact_words, compact_off, slot_off=None, uniform_slot_words=0):
+        _check(lib().gtsc_compact_device(self._h, nwords.numel(), _dp(slot_words), _dp(slot_off),
+                                         int(uniform_slot_words), _dp(nwords), _dp(compact_words), _dp(compact_off)))
+
+    # ---- host memory -----------------------------------------------------
+    def encode_host(self, block_ts, ts, val, pt_off=None, uniform_npoints=0, fmt=FMT_V2, capacity_words=None):
+        """numpy in, numpy out: returns (words, off) with the images back to back."""
+        block_ts = np.ascontiguousarray(block_ts, dtype=np.int64)
+        ts = np.ascontiguousarray(ts, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.uint64)
+        S = len(block_ts)
+        if pt_off is not None:
+            pt_off = np.ascontiguousarray(pt_off, dtype=np.uint64)
+            lens = np.diff(pt_off.astype(np.int64))
+        else:
+            lens = np.full(S, int(uniform_npoints), dtype=np.int64)
+        if capacity_words is None:
+            bits = 64 + np.where(lens > 0, 91 + 114 * (lens - 1), 0) + 37
+            capacity_words = int((bits // 64 + 2).sum())
+        out = np.zeros(max(capacity_words, 1), dtype=np.uint64)
+        off = np.zeros(S + 1, dtype=np.uint64)
+        _check(lib().gtsc_encode_host(self._h, fmt, S, _hp(block_ts), _hp(ts), _hp(val), _hp(pt_off),
+                                      int(uniform_npoints), _hp(out), int(capacity_words), _hp(off)))
+        return out[: int(off[-1])], off
+
+    def decode_host(self, words, in_off, pt_off=None, uniform_capacity=0, fmt=FMT_V2, check=True):
+        """numpy in, numpy out: returns (ts, val, npoints, status)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        S = len(in_off) - 1
+        if pt_off is not None:
+            pt_off = np.ascontiguousarray(pt_off, dtype=np.uint64)
+            total = int(pt_off[-1])
+        else:
+            total = S * int(uniform_capacity)
+        ts = np.zeros(total, dtype=np.int64)
+        val = np.zeros(total, dtype=np.uint64)
+        npts = np.zeros(S, dtype=np.uint64)
+        st = np.zeros(S, dtype=np.uint32)
+        rc = lib().gtsc_decode_host(self._h, fmt, S, _hp(words), _hp(in_off), _hp(ts), _hp(val), _hp(pt_off),
+                                    int(uniform_capacity), _hp(npts), _hp(st))
+        if check:
+            _check(rc)
+        return ts, val, npts, st

@@ -1,0 +1,174 @@
+/*
+ * gtsc -- Gorilla time-series codec for AMD Instinct MI355X (gfx950), C ABI.
+ *
+ * Batch-shaped drop-in for the compress/decompress path of burmanm/gorilla-tsc.
+ * The reference has no FFI; its public Java classes are the boundary, and each
+ * entry point below names the reference interface it stands in for ("G/" =
+ * src/main/java/fi/iki/yak/ts/compression/gorilla/ in the reference tree).
+ * One reference compressor instance handles one series block; one call here
+ * handles many independent blocks ("series") at once.
+ *
+ * Data layout (all little-endian host/device memory, plain arrays):
+ *   block_ts[S]      int64   block start timestamp per series (constructor arg of
+ *                            GorillaCompressor, G/GorillaCompressor.java:28-37)
+ *   ts[], val[]      int64 / uint64, points of all series back to back; val holds
+ *                            Double.doubleToRawLongBits(v) or the long itself
+ *                            (addValue, G/GorillaCompressor.java:49-71)
+ *   pt_off[S+1]      uint64  series s owns points [pt_off[s], pt_off[s+1])
+ *   words[]          uint64  compressed images; word i of an image equals element
+ *                            i of LongArrayOutput.getLongArray()
+ *                            (G/LongArrayOutput.java:141-145), i.e. stream bit k
+ *                            is bit 63-(k%64) of word k/64
+ *   *_off[S+1]       uint64  image of series s lives in slot
+ *                            [off[s], off[s+1]) of words[]; nwords[s] says how
+ *                            many words of the slot are the image
+ * Passing NULL for an offset array selects the uniform layout given by the
+ * accompanying uniform_* argument (every series has that many points / words).
+ *
+ * All "device" entry points take device pointers, enqueue on the context's
+ * stream and return without waiting; per-series problems are reported in
+ * status[] (optional) and summarised by gtsc_sync().
+ */
+#ifndef GTSC_H
+#define GTSC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes */
+#define GTSC_OK            0
+#define GTSC_ERR_ARG      (-1)  /* NULL / inconsistent argument */
+#define GTSC_ERR_CAPACITY (-2)  /* some series did not fit its output slot */
+#define GTSC_ERR_HIP      (-3)  /* HIP runtime error, see gtsc_last_error() */
+#define GTSC_ERR_STREAM   (-4)  /* some compressed image was truncated or malformed */
+
+/* stream formats */
+#define GTSC_FMT_V2 0  /* GorillaCompressor / GorillaDecompressor (2.x) */
+#define GTSC_FMT_V1 1  /* Compressor / Decompressor (1.x) */
+
+/* per-series status bits */
+#define GTSC_ST_OVERFLOW  1u  /* output slot too small; output for that series is incomplete */
+#define GTSC_ST_TRUNCATED 2u  /* decoder ran off the image: Java would throw
+                                 ArrayIndexOutOfBoundsException (G/LongArrayInput.java:44) */
+#define GTSC_ST_MALFORMED 4u  /* window reused before any was defined: Java would throw on the
+                                 mask-table index (G/LongArrayInput.java:60) */
+
+typedef struct gtsc_ctx gtsc_ctx;
+
+/* Library/ABI version (major*1000 + minor). */
+int gtsc_version(void);
+
+/* Thread-local description of the last error returned on this thread. */
+const char *gtsc_last_error(void);
+
+/* Worst-case image size in words for a block of npoints points: 36+78 = 114
+ * bits per point after the first, plus header, first point, close marker and
+ * the trailing word(s) of getLongArray().  No reference counterpart
+ * (LongArrayOutput grows by doubling, G/LongArrayOutput.java:58-62). */
+uint64_t gtsc_max_words(uint64_t npoints);
+
+/* A context owns one HIP stream on one device and a little scratch.  One per
+ * host thread and device, like the reference's per-instance, non-thread-safe
+ * objects.  device_id < 0 selects the current device. */
+int gtsc_create(int device_id, gtsc_ctx **ctx);
+int gtsc_destroy(gtsc_ctx *ctx);
+
+/* Enqueue on a caller-owned hipStream_t instead of the context's own
+ * (NULL restores the context's stream). */
+int gtsc_set_stream(gtsc_ctx *ctx, void *hip_stream);
+
+/* Wait for everything enqueued through ctx; returns GTSC_ERR_CAPACITY or
+ * GTSC_ERR_STREAM if any series of any call since the last sync raised a
+ * status bit, else GTSC_OK. */
+int gtsc_sync(gtsc_ctx *ctx);
+
+/*
+ * Compress nseries blocks.  Stands in for, per series s:
+ *   new GorillaCompressor(block_ts[s], new LongArrayOutput())   G/GorillaCompressor.java:28-37
+ *   addValue(ts[i], val[i]) for i in the series                 G/GorillaCompressor.java:49-71
+ *   close(); getLongArray()                                     G/GorillaCompressor.java:84-89,
+ *                                                               G/LongArrayOutput.java:141-145
+ * (GTSC_FMT_V1: Compressor, G/Compressor.java:24-84.)
+ * out_nwords[s] receives the image length; the image is written to
+ * out_words + out_off[s] (or + s*uniform_slot_words).
+ */
+int gtsc_encode_device(gtsc_ctx *ctx, int format, uint64_t nseries,
+                       const int64_t *block_ts,
+                       const int64_t *ts, const uint64_t *val,
+                       const uint64_t *pt_off, uint64_t uniform_npoints,
+                       uint64_t *out_words,
+                       const uint64_t *out_off, uint64_t uniform_slot_words,
+                       uint64_t *out_nwords, uint32_t *status);
+
+/*
+ * Decompress nseries images.  Stands in for, per series s:
+ *   new GorillaDecompressor(new LongArrayInput(image))          G/GorillaDecompressor.java:23-35
+ *   readPair() until null                                       G/GorillaDecompressor.java:42-49
+ * (GTSC_FMT_V1: Decompressor, G/Decompressor.java:22-42.)
+ * Pairs come back as structure-of-arrays (Pair.getTimestamp / getLongValue,
+ * G/Pair.java:8-28) at ts/val + pt_off[s] (or + s*uniform_capacity);
+ * out_npoints[s] receives the number of pairs before end of stream.
+ * in_nwords may be NULL: the whole slot is then taken as the image.
+ */
+int gtsc_decode_device(gtsc_ctx *ctx, int format, uint64_t nseries,
+                       const uint64_t *words,
+                       const uint64_t *in_off, uint64_t uniform_slot_words,
+                       const uint64_t *in_nwords,
+                       int64_t *ts, uint64_t *val,
+                       const uint64_t *pt_off, uint64_t uniform_capacity,
+                       uint64_t *out_npoints, uint32_t *status);
+
+/*
+ * Pack slotted images back to back: compact_off[0] = 0,
+ * compact_off[s+1] = compact_off[s] + nwords[s], and the image of s copied to
+ * compact_words + compact_off[s].  No reference counterpart (each Java block
+ * owns its own long[]); this is what a caller uses to persist a batch.
+ * compact_words must hold sum(nwords) words.
+ */
+int gtsc_compact_device(gtsc_ctx *ctx, uint64_t nseries,
+                        const uint64_t *slot_words,
+                        const uint64_t *slot_off, uint64_t uniform_slot_words,
+                        const uint64_t *nwords,
+                        uint64_t *compact_words, uint64_t *compact_off);
+
+/*
+ * Host-memory forms: every pointer is host memory and the call returns when
+ * the results are in the caller's arrays.  The batch is cut into chunks of
+ * whole series; each chunk is copied in, coded and copied out on one of two
+ * alternating streams so that copies overlap kernels.  Host arrays obtained
+ * from gtsc_host_alloc() are page-locked and move by DMA at PCIe rate; other
+ * memory works but is staged by the HIP runtime.
+ *
+ * Encode produces the images back to back: out_off[0] = 0, out_off[s+1] =
+ * out_off[s] + (image length of s), image s at out_words + out_off[s].
+ * out_capacity_words is the room in out_words; if the batch needs more the
+ * call returns GTSC_ERR_CAPACITY (out_off is still complete, so out_off[S]
+ * tells the room required).
+ * Decode reads such back-to-back images (in_off[S+1]) and fills ts/val slots
+ * exactly as gtsc_decode_device does.
+ */
+int gtsc_encode_host(gtsc_ctx *ctx, int format, uint64_t nseries,
+                     const int64_t *block_ts,
+                     const int64_t *ts, const uint64_t *val,
+                     const uint64_t *pt_off, uint64_t uniform_npoints,
+                     uint64_t *out_words, uint64_t out_capacity_words,
+                     uint64_t *out_off);
+
+int gtsc_decode_host(gtsc_ctx *ctx, int format, uint64_t nseries,
+                     const uint64_t *words, const uint64_t *in_off,
+                     int64_t *ts, uint64_t *val,
+                     const uint64_t *pt_off, uint64_t uniform_capacity,
+                     uint64_t *out_npoints, uint32_t *status);
+
+/* Page-locked host memory for the host entry points (hipHostMalloc/hipHostFree). */
+void *gtsc_host_alloc(size_t bytes);
+void gtsc_host_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTSC_H */

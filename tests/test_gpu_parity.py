@@ -1,0 +1,356 @@
+"""GPU parity suite: the HIP path, called through the C ABI (ctypes), against the
+CPU oracle on the same inputs -- bit-exact on compressed words, decoded
+timestamps, decoded value bits, counts and status words.  torch is used only
+to own device memory."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import pyoracle as O  # noqa: E402
+import pygtsc as G  # noqa: E402
+from pygtsc import synth  # noqa: E402
+
+FMTS = [(G.FMT_V2, O.V2), (G.FMT_V1, O.V1)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    c = G.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else np.ascontiguousarray(a))
+    return t.cuda()
+
+
+def host_u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def slot_offsets(b, tight=None):
+    lens = np.diff(b.pt_off.astype(np.int64))
+    bits = 64 + np.where(lens > 0, 91 + 114 * (lens - 1), 0) + 37
+    words = bits // 64 + 2 if tight is None else np.asarray(tight, dtype=np.int64)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(words, out=off[1:])
+    return off
+
+
+def gpu_encode(ctx, b, gfmt, uniform=False, out_off=None, want_status=True):
+    S = b.nseries
+    d_block, d_ts, d_val = dev(b.block_ts), dev(b.ts), dev(b.val)
+    d_nw = torch.zeros(S, dtype=torch.int64, device="cuda")
+    d_st = torch.full((S,), 77, dtype=torch.int32, device="cuda") if want_status else None
+    if uniform:
+        P = b.uniform_npoints()
+        assert P is not None
+        slot = G.max_words(P)
+        out_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(slot)
+        d_out = torch.full((S * slot,), -1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.encode_device(d_block, d_ts, d_val, d_out, d_nw, uniform_npoints=P, uniform_slot_words=slot, status=d_st,
+                          fmt=gfmt)
+    else:
+        if out_off is None:
+            out_off = slot_offsets(b)
+        d_out = torch.full((int(out_off[-1]),), -1, dtype=torch.int64, device="cuda")
+        d_po, d_oo = dev(b.pt_off), dev(out_off)
+        torch.cuda.synchronize()
+        ctx.encode_device(d_block, d_ts, d_val, d_out, d_nw, pt_off=d_po, out_off=d_oo, status=d_st, fmt=gfmt)
+    try:
+        ctx.sync()
+        rc = 0
+    except G.GtscError as e:
+        rc = e.code
+    st = d_st.cpu().numpy().view(np.uint32) if want_status else None
+    return host_u64(d_out), out_off, host_u64(d_nw), st, rc, d_out, d_nw
+
+
+def check_encode_against_oracle(ctx, b, gfmt, ofmt, uniform=False):
+    out, off, nw, st, rc, d_out, d_nw = gpu_encode(ctx, b, gfmt, uniform=uniform)
+    assert rc == 0 and not st.any()
+    ref_out, ref_off, ref_nw, ref_st = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, out_off=off, fmt=ofmt,
+                                                      nthreads=8)
+    assert np.array_equal(nw, ref_nw)
+    # compare exactly the image words of every series
+    idx = np.repeat(off[:-1].astype(np.int64), nw.astype(np.int64)) + (
+        np.arange(int(nw.sum())) - np.repeat(np.cumsum(nw.astype(np.int64)) - nw.astype(np.int64), nw.astype(np.int64)))
+    assert np.array_equal(out[idx], ref_out[idx])
+    return out, off, nw, d_out, d_nw
+
+
+def gpu_decode(ctx, words, in_off, in_nw, pt_off, gfmt, uniform_cap=None, d_words=None):
+    S = len(in_off) - 1
+    d_w = dev(words) if d_words is None else d_words
+    d_io = dev(in_off)
+    d_inw = dev(in_nw) if in_nw is not None else None
+    total = int(pt_off[-1]) if uniform_cap is None else S * uniform_cap
+    d_ts = torch.full((max(total, 1),), -7, dtype=torch.int64, device="cuda")
+    d_val = torch.full((max(total, 1),), -7, dtype=torch.int64, device="cuda")
+    d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
+    d_st = torch.full((S,), 77, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    if uniform_cap is None:
+        ctx.decode_device(d_w, d_ts, d_val, d_np, S, in_off=d_io, in_nwords=d_inw, pt_off=dev(pt_off), status=d_st, fmt=gfmt)
+    else:
+        ctx.decode_device(d_w, d_ts, d_val, d_np, S, in_off=d_io, in_nwords=d_inw, uniform_capacity=uniform_cap,
+                          status=d_st, fmt=gfmt)
+    try:
+        ctx.sync()
+        rc = 0
+    except G.GtscError as e:
+        rc = e.code
+    return d_ts.cpu().numpy()[:total], host_u64(d_val)[:total], host_u64(d_np), d_st.cpu().numpy().view(np.uint32), rc
+
+
+# --------------------------------------------------------------------------
+def test_known_answer_vectors(ctx, golden):
+    for gfmt, name in ((G.FMT_V2, "v2"), (G.FMT_V1, "v1")):
+        cases = [(k, c) for k, c in golden["answers"].items() if c["format"] == name and c["closed"]]
+        lens = [len(c["ts"]) for _, c in cases]
+        pt_off = np.zeros(len(cases) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=pt_off[1:])
+        b = synth.Batch(np.array([c["block_ts"] for _, c in cases], dtype=np.int64),
+                        np.array([t for _, c in cases for t in c["ts"]], dtype=np.int64),
+                        np.array([v for _, c in cases for v in c["val_bits"]], dtype=np.uint64), pt_off)
+        out, off, nw, st, rc, _, _ = gpu_encode(ctx, b, gfmt)
+        assert rc == 0 and not st.any()
+        for i, (k, c) in enumerate(cases):
+            img = out[int(off[i]): int(off[i]) + int(nw[i])]
+            assert ["%016x" % int(x) for x in img] == c["words_hex"], k
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_reference_test_inputs_round_trip(ctx, golden, gfmt, ofmt):
+    inp = golden["inputs"]
+    d2u = lambda x: struct.unpack("<Q", struct.pack("<d", float(x)))[0]
+    sets = [(inp["willItBlend"]["block_ts"], inp["willItBlend"]["ts"], inp["willItBlend"]["val_bits"])]
+    for k in ("simple", "similarFloats"):
+        sets.append((inp[k]["block_ts"], [inp[k]["block_ts"] + o for o in inp[k]["offsets"]],
+                     [d2u(x) for x in inp[k]["doubles"]]))
+    sets.append((1500400800000, [], []))  # testEmptyBlock
+    pt_off = np.zeros(len(sets) + 1, dtype=np.uint64)
+    np.cumsum([len(s[1]) for s in sets], out=pt_off[1:])
+    b = synth.Batch(np.array([s[0] for s in sets], dtype=np.int64), np.array([t for s in sets for t in s[1]], dtype=np.int64),
+                    np.array([v for s in sets for v in s[2]], dtype=np.uint64), pt_off)
+    out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt)
+    ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, gfmt)
+    assert rc == 0 and not st.any()
+    assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+    assert np.array_equal(npts.astype(np.int64), np.diff(b.pt_off.astype(np.int64)))
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ragged_batches_match_oracle(ctx, gfmt, ofmt, seed):
+    b = synth.ragged_mix(seed=seed, nseries=1000, pmax=400)
+    out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt)
+    ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, gfmt)
+    rts, rval, rnp, rst = O.decode_batch(out, off, nw, b.pt_off, fmt=ofmt, nthreads=8)
+    assert rc == 0 and np.array_equal(st, rst) and np.array_equal(npts, rnp)
+    assert np.array_equal(ts, rts) and np.array_equal(val, rval)
+    assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+
+
+GENS = [
+    ("random_walk", lambda: synth.random_walk(S=96, P=7200)),
+    ("quantised_walk", lambda: synth.quantised_walk(S=96, P=7200)),
+    ("gauge_integer", lambda: synth.gauge_integer(S=20000, P=120)),
+    ("gauge_drift", lambda: synth.gauge_drift(S=20000, P=120)),
+    ("adversarial", lambda: synth.adversarial(S=130, P=3000)),
+    ("readme", lambda: synth.readme_workload(S=3, P=100000)),
+    ("skewed", lambda: synth.skewed(total_points=1 << 20)),
+    ("word_edges", lambda: synth.random_walk(S=300, P=63)),
+]
+
+
+@pytest.mark.parametrize("name,gen", GENS, ids=[g[0] for g in GENS])
+def test_benchmark_shapes_match_oracle(ctx, name, gen):
+    b = gen()
+    for gfmt, ofmt in FMTS:
+        uniform = b.uniform_npoints() is not None
+        out, off, nw, d_out, d_nw = check_encode_against_oracle(ctx, b, gfmt, ofmt, uniform=uniform)
+        cap = b.uniform_npoints() if uniform else None
+        ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, gfmt, uniform_cap=cap, d_words=d_out)
+        assert rc == 0 and not st.any()
+        assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+        assert np.array_equal(npts.astype(np.int64), np.diff(b.pt_off.astype(np.int64)))
+
+
+def test_uniform_and_csr_layouts_agree(ctx):
+    b = synth.gauge_drift(S=5000, P=120)
+    o1 = gpu_encode(ctx, b, G.FMT_V2, uniform=True)
+    o2 = gpu_encode(ctx, b, G.FMT_V2, uniform=False)
+    assert np.array_equal(o1[2], o2[2])
+    nw = o1[2].astype(np.int64)
+    for s in (0, 1, 77, 4999):
+        a = o1[0][int(o1[1][s]): int(o1[1][s]) + nw[s]]
+        c = o2[0][int(o2[1][s]): int(o2[1][s]) + nw[s]]
+        assert np.array_equal(a, c)
+
+
+def test_compaction(ctx):
+    b = synth.ragged_mix(seed=11, nseries=3000, pmax=150)
+    out, off, nw, d_out, d_nw = check_encode_against_oracle(ctx, b, G.FMT_V2, O.V2)
+    S = b.nseries
+    total = int(nw.sum())
+    d_c = torch.full((total,), -1, dtype=torch.int64, device="cuda")
+    d_co = torch.full((S + 1,), -1, dtype=torch.int64, device="cuda")
+    ctx.compact_device(d_out, d_nw, d_c, d_co, slot_off=dev(off))
+    ctx.sync()
+    co = host_u64(d_co)
+    expect = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum(nw, out=expect[1:])
+    assert np.array_equal(co, expect)
+    c = host_u64(d_c)
+    for s in range(0, S, 37):
+        assert np.array_equal(c[int(co[s]): int(co[s + 1])], out[int(off[s]): int(off[s]) + int(nw[s])])
+    # the compact form decodes as well (slot == image)
+    ts, val, npts, st, rc = gpu_decode(ctx, c, co, None, b.pt_off, G.FMT_V2)
+    assert rc == 0 and np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+
+
+def test_slot_overflow_is_reported(ctx):
+    b = synth.random_walk(S=200, P=500)
+    lens = np.full(200, 100, dtype=np.int64)  # far too small for 500 random-walk points
+    lens[::2] = G.max_words(500)
+    off = slot_offsets(b, tight=lens)
+    out, off, nw, st, rc, _, _ = gpu_encode(ctx, b, G.FMT_V2, out_off=off)
+    assert rc == G.ERR_CAPACITY
+    assert np.all(st[1::2] == G.ST_OVERFLOW) and not st[::2].any()
+    ref_out, _, ref_nw, ref_st = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, out_off=off)
+    assert np.array_equal(nw, ref_nw) and np.array_equal(st, ref_st)
+    # neighbours of an overflowing series are untouched
+    for s in range(0, 200, 2):
+        a = int(off[s])
+        assert np.array_equal(out[a: a + int(nw[s])], ref_out[a: a + int(nw[s])])
+
+
+def test_decode_capacity_overflow_and_bad_streams(ctx):
+    b = synth.random_walk(S=64, P=300)
+    out, off, nw, _, _ = check_encode_against_oracle(ctx, b, G.FMT_V2, O.V2)
+    # (1) capacity smaller than the series
+    ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, G.FMT_V2, uniform_cap=100)
+    assert rc == G.ERR_CAPACITY and np.all(st == G.ST_OVERFLOW) and np.all(npts == 300)
+    assert np.array_equal(ts.reshape(64, 100), b.ts.reshape(64, 300)[:, :100])
+    # (2) truncated images: same counts and status as the oracle
+    short = nw.copy()
+    short[::3] = short[::3] // 2
+    short[1::3] -= 1
+    short[5] = 0
+    ts, val, npts, st, rc = gpu_decode(ctx, out, off, short, b.pt_off, G.FMT_V2)
+    rts, rval, rnp, rst = O.decode_batch(out, off, short, b.pt_off)
+    assert rc == G.ERR_STREAM
+    assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+    for s in range(64):
+        a, n = int(b.pt_off[s]), int(npts[s])
+        assert np.array_equal(ts[a:a + n], rts[a:a + n]) and np.array_equal(val[a:a + n], rval[a:a + n])
+    # (3) window reuse before any window: malformed
+    import spec_codec as SP
+    B = 1500400800000
+    bits = format(B, "064b") + format(1000, "027b") + format(12345, "064b") + "0" + "10" + "1" * 40
+    w = np.array(SP.words_image(bits), dtype=np.uint64)
+    o = np.array([0, len(w)], dtype=np.uint64)
+    ts, val, npts, st, rc = gpu_decode(ctx, w, o, None, np.array([0, 10], dtype=np.uint64), G.FMT_V2)
+    rts, rval, rnp, rst = O.decode_batch(w, o, None, np.array([0, 10], dtype=np.uint64))
+    assert rc == G.ERR_STREAM and st[0] == rst[0] == G.ST_MALFORMED and npts[0] == rnp[0] == 1
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_quirks_first_ts_zero_and_int_wrap(ctx, gfmt, ofmt):
+    B = 1500400800000
+    series = [
+        (0, [0, 1000, 2000, 3000], [5, 6, 7, 7]),                       # storedTimestamp == 0 after the first add
+        (B, [B + 5, B + 5 + 2 ** 31 + 7, B + 5 + 2 ** 33], [1, 2, 3]),  # int overflow of the v2 delta
+        (B, [B + 2 ** 27 + 5, B + 2 ** 27 + 6], [9, 9]),                # first delta beyond 27 bits (masked)
+        (B, [B - 5, B + 6], [9, 10]),                                   # negative first delta
+    ]
+    pt_off = np.zeros(len(series) + 1, dtype=np.uint64)
+    np.cumsum([len(s[1]) for s in series], out=pt_off[1:])
+    b = synth.Batch(np.array([s[0] for s in series], dtype=np.int64),
+                    np.array([t for s in series for t in s[1]], dtype=np.int64),
+                    np.array([v for s in series for v in s[2]], dtype=np.uint64), pt_off)
+    out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt)
+    # decoders agree with each other even where the stream does not round-trip
+    cap = np.arange(len(series) + 1, dtype=np.uint64) * np.uint64(8)
+    ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, cap, gfmt)
+    rts, rval, rnp, rst = O.decode_batch(out, off, nw, cap, fmt=ofmt)
+    assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+    for s in range(len(series)):
+        a, n = int(cap[s]), int(min(npts[s], 8))
+        assert np.array_equal(ts[a:a + n], rts[a:a + n]) and np.array_equal(val[a:a + n], rval[a:a + n])
+
+
+def test_host_entry_points(ctx):
+    b = synth.ragged_mix(seed=5, nseries=2500, pmax=300)
+    for gfmt, ofmt in FMTS:
+        words, off = ctx.encode_host(b.block_ts, b.ts, b.val, pt_off=b.pt_off, fmt=gfmt)
+        ref_out, ref_off, ref_nw, _ = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, fmt=ofmt, nthreads=8)
+        expect_off = np.zeros(b.nseries + 1, dtype=np.uint64)
+        np.cumsum(ref_nw, out=expect_off[1:])
+        assert np.array_equal(off, expect_off)
+        for s in range(0, b.nseries, 13):
+            assert np.array_equal(words[int(off[s]): int(off[s + 1])],
+                                  ref_out[int(ref_off[s]): int(ref_off[s]) + int(ref_nw[s])])
+        ts, val, npts, st = ctx.decode_host(words, off, pt_off=b.pt_off, fmt=gfmt)
+        assert not st.any() and np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+    # uniform layout and too small an output buffer
+    u = synth.gauge_integer(S=3000, P=120)
+    words, off = ctx.encode_host(u.block_ts, u.ts, u.val, uniform_npoints=120)
+    ts, val, npts, st = ctx.decode_host(words, off, uniform_capacity=120)
+    assert np.array_equal(ts, u.ts) and np.array_equal(val, u.val) and np.all(npts == 120)
+    with pytest.raises(G.GtscError) as ei:
+        ctx.encode_host(u.block_ts, u.ts, u.val, uniform_npoints=120, capacity_words=1000)
+    assert ei.value.code == G.ERR_CAPACITY
+
+
+def test_full_size_1m_series_round_trip(ctx):
+    """BASELINE config: 1M series x 120 points.  Too big for a word-by-word oracle
+    comparison in test time, so: (a) decode(encode(x)) == x on the device for all
+    120M points, (b) image lengths within the bound, (c) a strided sample of series
+    checked against the oracle byte for byte."""
+    S, P = 1_000_000, 120
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0002)
+    start = torch.randint(0, 1001, (S, 1), device="cuda", generator=g).double()
+    r = torch.rand((S, P), device="cuda", generator=g)
+    step = torch.where(r < 0.05, -1.0, torch.where(r < 0.10, 1.0, 0.0)).double()
+    step[:, 0] = 0
+    v = (start + torch.cumsum(step, dim=1)).contiguous()
+    d_val = v.view(torch.int64).reshape(-1)
+    d_ts = (synth.BLOCK_TS + 60000 * torch.arange(1, P + 1, device="cuda", dtype=torch.int64)).repeat(S, 1).reshape(-1).contiguous()
+    d_block = torch.full((S,), synth.BLOCK_TS, dtype=torch.int64, device="cuda")
+    slot = G.max_words(P)
+    d_out = torch.zeros(S * slot, dtype=torch.int64, device="cuda")
+    d_nw = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_device(d_block, d_ts, d_val, d_out, d_nw, uniform_npoints=P, uniform_slot_words=slot)
+    ctx.sync()
+    assert int(d_nw.max()) <= slot and int(d_nw.min()) >= 3
+    d_ts2 = torch.zeros_like(d_ts)
+    d_val2 = torch.zeros_like(d_val)
+    d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
+    ctx.decode_device(d_out, d_ts2, d_val2, d_np, S, uniform_slot_words=slot, in_nwords=d_nw, uniform_capacity=P)
+    ctx.sync()
+    assert bool((d_np == P).all())
+    assert torch.equal(d_ts2, d_ts) and torch.equal(d_val2, d_val)
+    # sample against the oracle
+    idx = torch.arange(0, S, 997, device="cuda")
+    hb = synth.Batch(np.full(len(idx), synth.BLOCK_TS, dtype=np.int64),
+                     d_ts.view(S, P)[idx].reshape(-1).cpu().numpy(),
+                     d_val.view(S, P)[idx].reshape(-1).cpu().numpy().view(np.uint64),
+                     np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(P))
+    ref_out, ref_off, ref_nw, _ = O.encode_batch(hb.block_ts, hb.ts, hb.val, hb.pt_off, nthreads=8)
+    got = host_u64(d_out.view(S, slot)[idx])
+    got_nw = host_u64(d_nw[idx])
+    assert np.array_equal(got_nw, ref_nw)
+    for i in range(len(idx)):
+        n = int(ref_nw[i])
+        assert np.array_equal(got[i, :n], ref_out[int(ref_off[i]): int(ref_off[i]) + n])
