@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the device-resident Gorilla codec on MI355X.
+
+One "step" = compress one batch of series with the HIP encode kernel, then
+decompress the result with the HIP decode kernel, inputs and outputs resident
+in HBM.  Default workload: 1,000,000 series x 120 points (2 h at 60 s cadence)
+of gauge-like slowly varying doubles per GPU.  With --gpus N > 1 (launched by
+torch.distributed.run) every rank codes its own shard of series of the same
+size on its own GPU: series are independent, so there is no collective on the
+data path; the only communication is the barrier / MAX of the timing.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gorilla-tsc_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import pygtsc as G  # noqa: E402
+from pygtsc import synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def make_workload(name, S, P, device, seed):
+    """Synthetic series generated on the device.  Returns (block_ts, ts, val) int64 tensors."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if name == "gauge":
+        # integer-valued gauge: start U[0,1000], +-1 with probability 0.1 per step, 60 s cadence
+        cadence = 60000
+        start = torch.randint(0, 1001, (S, 1), device=device, generator=g).double()
+        r = torch.rand((S, P), device=device, generator=g)
+        step = torch.where(r < 0.05, -1.0, torch.where(r < 0.10, 1.0, 0.0)).double()
+        step[:, 0] = 0
+        v = start + torch.cumsum(step, dim=1)
+        del r, step
+    elif name == "gauge_drift":
+        # slow drift rounded to 2 decimals (about 33 bits/point)
+        cadence = 60000
+        start = torch.rand((S, 1), device=device, generator=g, dtype=torch.float64) * 1000
+        v = start + torch.cumsum(torch.randn((S, P), device=device, generator=g, dtype=torch.float64) * 0.05, dim=1)
+        v = torch.round(v * 100) / 100
+    elif name == "random_walk":
+        cadence = 1000
+        v = 100.0 + torch.cumsum(torch.randn((S, P), device=device, generator=g, dtype=torch.float64), dim=1)
+    elif name == "adversarial":
+        cadence = 1000
+        v = torch.randint(-2 ** 63, 2 ** 63 - 1, (S, P), device=device, generator=g, dtype=torch.int64).view(torch.float64)
+    else:
+        raise SystemExit("unknown workload %r" % name)
+    val = v.contiguous().view(torch.int64).reshape(-1)
+    ts_row = synth.BLOCK_TS + cadence * torch.arange(1, P + 1, device=device, dtype=torch.int64)
+    if name == "adversarial":
+        jit = torch.randint(-400, 400, (S, P), device=device, generator=g, dtype=torch.int64)
+        ts = (ts_row[None, :] + jit).reshape(-1).contiguous()
+    else:
+        ts = ts_row.repeat(S, 1).reshape(-1).contiguous()
+    block = torch.full((S,), synth.BLOCK_TS, dtype=torch.int64, device=device)
+    return block, ts, val
+
+
+def cpu_baseline(block, ts, val, P, sample_series, threads):
+    """The C oracle (a port of the reference algorithm), one codec instance per series,
+    series split over `threads` POSIX threads, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as O
+    S = min(sample_series, block.numel())
+    b = block[:S].cpu().numpy()
+    t = ts[: S * P].cpu().numpy()
+    v = val[: S * P].cpu().numpy().view(np.uint64)
+    pt_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(P)
+    best_e = best_d = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        out, off, nw, st = O.encode_batch(b, t, v, pt_off, nthreads=threads)
+        t1 = time.perf_counter()
+        dt, dv, npts, st2 = O.decode_batch(out, off, nw, pt_off, nthreads=threads)
+        t2 = time.perf_counter()
+        best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
+    assert np.array_equal(dt, t) and np.array_equal(dv, v)
+    raw = 16.0 * S * P
+    return {
+        "value": round(2 * raw / (best_e + best_d) / 1e9, 3),
+        "unit": "GB/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d series x %d points (%.0f MB raw), compress+decompress, best of 2" % (S, P, raw / 1e6),
+        "compress_GBps": round(raw / best_e / 1e9, 3),
+        "decompress_GBps": round(raw / best_d / 1e9, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="gauge")
+    ap.add_argument("--series", type=int, default=1_000_000)
+    ap.add_argument("--points", type=int, default=120)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-series", type=int, default=262144)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    S, P = args.series, args.points
+    block, ts, val = make_workload(args.workload, S, P, device, 0x5EED0002 + rank)
+    slot = G.max_words(P)
+    out = torch.zeros(S * slot, dtype=torch.int64, device=device)
+    nw = torch.zeros(S, dtype=torch.int64, device=device)
+    ts2 = torch.zeros_like(ts)
+    val2 = torch.zeros_like(val)
+    npts = torch.zeros(S, dtype=torch.int64, device=device)
+
+    ctx = G.Context(local_rank)
+    stream = torch.cuda.Stream(device=device)
+    ctx.set_stream(stream.cuda_stream)
+
+    def encode():
+        ctx.encode_device(block, ts, val, out, nw, uniform_npoints=P, uniform_slot_words=slot)
+
+    def decode():
+        ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P)
+
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            encode()
+            decode()
+    ctx.sync()
+    # parity guard on the very buffers that get timed
+    assert torch.equal(ts2, ts) and torch.equal(val2, val) and bool((npts == P).all()), "round trip failed"
+    total_words = int(nw.sum())
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for k in range(args.steps):
+            ev[k][0].record(stream)
+            encode()
+            ev[k][1].record(stream)
+            decode()
+            ev[k][2].record(stream)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    raw_bytes = 16.0 * S * P
+    # algorithmic bytes of one launch: raw points + compressed words + per-series block_ts and length
+    algo_bytes = raw_bytes + 8.0 * total_words + 16.0 * S
+    dom, dom_ms = ("encode", enc_ms) if enc_ms >= dec_ms else ("decode", dec_ms)
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "device-resident Gorilla compress/decompress GB/s of raw (ts,double) points",
+        "value": round(2 * raw_bytes * args.steps * world / elapsed / 1e9, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %d series x %d points per GPU, %s, uniform layout; step = compress + decompress" % (
+                args.workload, S, P, "v2 format"),
+            "series_per_gpu": S, "points_per_series": P,
+            "compressed_bits_per_point": round(64.0 * total_words / (S * P), 3),
+        },
+        "compress_GBps_per_gpu": round(raw_bytes / (enc_ms * 1e-3) / 1e9, 2),
+        "decompress_GBps_per_gpu": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 2),
+        "raw_only_frac_of_hbm_peak": {
+            "compress": round(raw_bytes / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "decompress": round(raw_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(dom_ms, 4),
+            "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(16, os.cpu_count() or 1)
+        result["cpu_baseline"] = cpu_baseline(block, ts, val, P, args.cpu_sample_series, threads)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

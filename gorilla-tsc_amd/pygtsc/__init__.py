@@ -41,6 +41,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libgtsc.so not built: run `make -C %s`" % os.path.dirname(LIB_PATH))
+    # One HIP runtime per process: the torch wheel carries its own libamdhip64
+    # (requested as "libamdhip64.so", soname libamdhip64.so.7).  Loaded first, it
+    # also satisfies libgtsc's "libamdhip64.so.7"; loaded second, the process
+    # would hold two runtimes and the later one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.gtsc_version.restype = i32

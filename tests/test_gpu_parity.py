@@ -337,6 +337,7 @@ def test_full_size_1m_series_round_trip(ctx):
     d_ts2 = torch.zeros_like(d_ts)
     d_val2 = torch.zeros_like(d_val)
     d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()  # the context has its own stream: torch's fills must land first
     ctx.decode_device(d_out, d_ts2, d_val2, d_np, S, uniform_slot_words=slot, in_nwords=d_nw, uniform_capacity=P)
     ctx.sync()
     assert bool((d_np == P).all())
