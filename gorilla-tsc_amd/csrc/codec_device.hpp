@@ -38,8 +38,13 @@ __device__ __forceinline__ uint32_t clz64(uint64_t x) { return (uint32_t)__built
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }  // x != 0
 
 // ---------------------------------------------------------------- encoder
-// Pending bits sit right-aligned in `acc` (exactly `nacc` low bits, zeros above).
+// Pending bits sit left-aligned in `acc` (its top `nacc` bits, zeros below).
 // A completed 64-bit word is handed to the sink: sink(word_index, word).
+// The per-point path is written with selects instead of branches: 64 series
+// advance in lock step and take different code paths at every point, so a
+// branchy form pays for every path anyway plus the exec-mask bookkeeping.
+// put() keeps the dependency chain through `acc` to an OR and a select: the
+// shifts depend only on the bit count, which runs ahead as a chain of adds.
 template <int FMT>
 struct Encoder {
     uint64_t acc;
@@ -54,18 +59,15 @@ struct Encoder {
     template <class Sink>
     __device__ __forceinline__ void put(uint64_t v, uint32_t n, Sink& sink)
     {
-        uint32_t total = nacc + n;
-        if (total < 64) {
-            acc = (acc << (n & 63)) | v;
-            nacc = total;
-        } else {
-            uint32_t spill = total - 64;            // 0..63
-            uint64_t word = (acc << ((64 - nacc) & 63)) | (v >> spill);
-            sink(widx, word);
-            widx++;
-            acc = v & ((1ull << spill) - 1ull);
-            nacc = spill;
-        }
+        const uint64_t va = v << ((64 - n) & 63);          // left-aligned code (n == 0: v == 0)
+        const uint64_t word = acc | (va >> nacc);
+        const uint64_t rest = (va << 1) << (63 - nacc);    // what did not fit (nacc == 0: nothing)
+        const uint32_t total = nacc + n;
+        const bool full = total >= 64;
+        if (full) sink(widx, word);
+        widx += full ? 1u : 0u;
+        acc = full ? rest : word;
+        nacc = total & 63;
     }
 
     template <class Sink>
@@ -80,7 +82,7 @@ struct Encoder {
     template <class Sink>
     __device__ __forceinline__ void add(int64_t block_ts, int64_t ts, uint64_t v, Sink& sink)
     {
-        if (stored_ts == 0) {
+        if (__builtin_expect(stored_ts == 0, 0)) {
             // writeFirst: 27 low bits of the delta, then the raw value
             uint64_t d = (uint64_t)ts - (uint64_t)block_ts;
             stored_delta = (FMT == FMT_V2) ? (int64_t)(int32_t)(uint32_t)d : (int64_t)d;
@@ -90,53 +92,59 @@ struct Encoder {
             put(v, 64, sink);
             return;
         }
-        // ---- timestamp: code `tcode` of `tlen` bits
-        uint64_t tcode;
-        uint32_t tlen;
+        add_next(ts, v, sink);
+    }
+
+    // A point that is known not to be a "first" point (stored_ts != 0): straight-line code.
+    template <class Sink>
+    __device__ __forceinline__ void add_next(int64_t ts, uint64_t v, Sink& sink)
+    {
+        // ---- timestamp: code (thi:tlo) of tlen bits
+        uint32_t tlo, thi, tlen;
         if (FMT == FMT_V2) {
             // int arithmetic: only the low 32 bits of the timestamps take part
-            int32_t nd = (int32_t)((uint32_t)ts - (uint32_t)stored_ts);
-            int32_t dod = (int32_t)((uint32_t)nd - (uint32_t)(int32_t)stored_delta);
-            uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
-            uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0
-            if (dod == 0)                     { tcode = 0; tlen = 1; }
-            else if (need >= 1 && need <= 7)  { tcode = 0x100u | z; tlen = 9; }
-            else if (need >= 8 && need <= 9)  { tcode = 0xC00u | z; tlen = 12; }
-            else if (need >= 10 && need <= 12){ tcode = 0xE000u | z; tlen = 16; }
-            else                              { tcode = (0xFull << 32) | z; tlen = 36; }  // need 0 (dod -1) or > 12
-            stored_delta = nd;
+            const uint32_t nd = (uint32_t)ts - (uint32_t)stored_ts;
+            const int32_t dod = (int32_t)(nd - (uint32_t)(int32_t)stored_delta);
+            const uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
+            const uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0
+            const bool zero = dod == 0;
+            const bool b7 = (need - 1u) < 7u, b9 = (need - 8u) < 2u, b12 = (need - 10u) < 3u;
+            tlen = zero ? 1u : b7 ? 9u : b9 ? 12u : b12 ? 16u : 36u;  // need 0 (dod -1) or > 12: 36
+            const uint32_t pre = b7 ? 0x100u : b9 ? 0xC00u : b12 ? 0xE000u : 0u;
+            tlo = zero ? 0u : (z | pre);
+            thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
+            stored_delta = (int64_t)(int32_t)nd;
         } else {
-            int64_t nd = (int64_t)((uint64_t)ts - stored_ts);
-            int64_t dod = (int64_t)((uint64_t)nd - (uint64_t)stored_delta);
-            if (dod == 0)                         { tcode = 0; tlen = 1; }
-            else if (dod >= -63 && dod <= 64)     { tcode = 0x100u | ((uint64_t)dod & 0x7F); tlen = 9; }
-            else if (dod >= -255 && dod <= 256)   { tcode = 0xC00u | ((uint64_t)dod & 0x1FF); tlen = 12; }
-            else if (dod >= -2047 && dod <= 2048) { tcode = 0xE000u | ((uint64_t)dod & 0xFFF); tlen = 16; }
-            else                                  { tcode = (0xFull << 32) | ((uint64_t)dod & 0xFFFFFFFFull); tlen = 36; }
-            stored_delta = nd;
+            const uint64_t nd = (uint64_t)ts - stored_ts;
+            const uint64_t dod = nd - (uint64_t)stored_delta;
+            const bool zero = dod == 0;
+            const bool b7 = (dod + 63u) <= 127u, b9 = (dod + 255u) <= 511u, b12 = (dod + 2047u) <= 4095u;
+            tlen = zero ? 1u : b7 ? 9u : b9 ? 12u : b12 ? 16u : 36u;
+            const uint32_t lo = (uint32_t)dod;
+            tlo = zero ? 0u : b7 ? (0x100u | (lo & 0x7Fu)) : b9 ? (0xC00u | (lo & 0x1FFu)) : b12 ? (0xE000u | (lo & 0xFFFu)) : lo;
+            thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
+            stored_delta = (int64_t)nd;
         }
         stored_ts = (uint64_t)ts;
-        // ---- value: header `vh` of `vhlen` bits, payload `pay` of `plen` bits
-        uint64_t x = prev ^ v;
+        // ---- value: header vh of vhlen bits, payload pay of plen bits
+        const uint64_t x = prev ^ v;
         prev = v;
-        uint32_t vh, vhlen, plen;
-        uint64_t pay;
-        if (x == 0) {
-            vh = 0; vhlen = 1; pay = 0; plen = 0;
-        } else {
-            uint32_t lz = clz64(x), tz = ctz64(x);
-            if (FMT == FMT_V1 && lz >= 32) lz = 31;  // G/Compressor.java:132-134
-            if (lz >= lead && tz >= trail) {
-                vh = 2; vhlen = 2;
-                pay = x >> trail; plen = 64 - lead - trail;
-            } else {
-                uint32_t sig = 64 - lz - tz;
-                if (FMT == FMT_V2) { vh = (3u << 12) | (lz << 6) | (sig - 1); vhlen = 14; }
-                else               { vh = (3u << 11) | (lz << 6) | (sig & 63); vhlen = 13; }
-                pay = x >> tz; plen = sig;
-                lead = lz; trail = tz;
-            }
-        }
+        const bool nz = x != 0;
+        uint32_t lz = (uint32_t)__clzll((long long)x);         // 64 when x == 0 (unused then)
+        const uint32_t tz = (uint32_t)(__ffsll((long long)x) - 1);
+        if (FMT == FMT_V1) lz = lz >= 32 ? 31u : lz;           // G/Compressor.java:132-134
+        const bool reuse = nz && lz >= lead && tz >= trail;
+        const bool fresh = nz && !reuse;
+        const uint32_t sig = 64u - lz - tz;
+        const uint32_t sh = reuse ? trail : tz;
+        const uint64_t pay = x >> (sh & 63);                    // x == 0 gives 0 whatever the count
+        const uint32_t plen = nz ? (reuse ? 64u - lead - trail : sig) : 0u;
+        const uint32_t vh_new = (FMT == FMT_V2) ? ((3u << 12) | (lz << 6) | (sig - 1u)) : ((3u << 11) | (lz << 6) | (sig & 63u));
+        const uint32_t vh = nz ? (reuse ? 2u : vh_new) : 0u;
+        const uint32_t vhlen = nz ? (reuse ? 2u : (FMT == FMT_V2 ? 14u : 13u)) : 1u;
+        lead = fresh ? lz : lead;
+        trail = fresh ? tz : trail;
+        const uint64_t tcode = ((uint64_t)thi << 32) | tlo;
         put((tcode << vhlen) | vh, tlen + vhlen, sink);  // <= 36 + 14 bits
         put(pay, plen, sink);
     }
@@ -147,8 +155,7 @@ struct Encoder {
     __device__ __forceinline__ uint32_t finish(Sink& sink)
     {
         put((0xFFFFFFFFFull << 1), 37, sink);  // '1111' + 32 ones + '0'
-        if (nacc) { sink(widx, acc << (64 - nacc)); widx++; }
-        else      { sink(widx, 0ull); widx++; }
+        sink(widx, acc); widx++;  // the partial word, or a zero word when the stream ended on a boundary
         sink(widx, 0ull); widx++;
         return widx;
     }
@@ -156,10 +163,15 @@ struct Encoder {
 
 // ---------------------------------------------------------------- decoder
 // Source: src(word_index) -> word, returning 0 beyond the image.
-// `w0` holds word widx, `w1` word widx+1, `off` the bit offset inside w0.
+// r0..r3 hold words widx..widx+3 of the image, `off` is the bit offset of the
+// next unread bit inside r0.  One point needs at most 63 + 114 bits, i.e. r0..r2;
+// r3 is look-ahead so that the load issued when the window slides is not needed
+// before the following point.  All fields of a point are extracted speculatively
+// with selects; the rare outcomes (end of stream, truncation, malformed) share
+// one branch.
 template <int FMT>
 struct Decoder {
-    uint64_t w0, w1;
+    uint64_t r0, r1, r2, r3;
     uint32_t widx, off, nwords;
     uint32_t st;
     int64_t block_ts, stored_delta;
@@ -167,37 +179,46 @@ struct Decoder {
     uint32_t lead;
     int32_t trail;
 
-    __device__ __forceinline__ uint64_t peek() const
+    // 64 bits starting o bits into the window, o in [0,127]
+    __device__ __forceinline__ uint64_t peek_at(uint32_t o) const
     {
-        return off ? ((w0 << off) | (w1 >> (64 - off))) : w0;
+        const bool up = o >= 64;
+        const uint64_t a = up ? r1 : r0, b = up ? r2 : r1;
+        const uint32_t s = o & 63;
+        return (a << s) | ((b >> 1) >> (63 - s));
     }
+    // slide the window by o bits, o in [0,191]
     template <class Src>
-    __device__ __forceinline__ void skip(uint32_t n, Src& src)  // n in [0,64]
+    __device__ __forceinline__ void advance(uint32_t o, Src& src)
     {
-        off += n;
-        if (off >= 64) {
-            off -= 64;
-            widx++;
-            w0 = w1;
-            w1 = src(widx + 1);
+        const uint32_t k = o >> 6;  // 0..2 words
+        off = o & 63;
+        if (k) {
+            const uint64_t n0 = src(widx + 4), n1 = (k == 2) ? src(widx + 5) : 0ull;
+            const bool two = k == 2;
+            r0 = two ? r2 : r1;
+            r1 = two ? r3 : r2;
+            r2 = two ? n0 : r3;
+            r3 = two ? n1 : n0;
+            widx += k;
         }
     }
-    // a read that ends at or beyond the last bit of the image is what makes
-    // LongArrayInput throw (eager load of the next word, G/LongArrayInput.java:48-52)
-    __device__ __forceinline__ bool ran_off() const { return widx >= nwords; }
+    // A read that ends at or beyond the last bit of the image is what makes
+    // LongArrayInput throw (eager load of the next word, G/LongArrayInput.java:48-52):
+    // true when a field ending o bits into the window runs off the image.
+    __device__ __forceinline__ bool runs_off(uint32_t o) const { return widx + (o >> 6) >= nwords; }
 
     template <class Src>
     __device__ __forceinline__ void begin(uint32_t nwords_, Src& src)
     {
         nwords = nwords_;
-        st = nwords ? 0u : ST_TRUNCATED;
         widx = 0; off = 0;
-        w0 = src(0); w1 = src(1);
+        r0 = src(0); r1 = src(1); r2 = src(2); r3 = src(3);
         stored_ts = 0; stored_delta = 0; val = 0;
         lead = NO_WINDOW; trail = 0;
-        block_ts = (int64_t)peek();
-        skip(64, src);
-        if (ran_off()) st |= ST_TRUNCATED;
+        block_ts = (int64_t)r0;
+        st = runs_off(64) ? ST_TRUNCATED : 0u;  // also covers nwords == 0
+        advance(64, src);
     }
 
     // Decodes the next pair into (ts_out, val_out).  Returns true when a pair
@@ -206,76 +227,79 @@ struct Decoder {
     __device__ __forceinline__ bool next(int64_t& ts_out, uint64_t& val_out, Src& src)
     {
         if (st) return false;
-        uint64_t top = peek();
-        if (stored_ts == 0) {
-            uint32_t d = (uint32_t)(top >> 37);
-            skip(27, src);
-            if (ran_off()) { st |= ST_TRUNCATED; return false; }
+        if (__builtin_expect(stored_ts == 0, 0)) {
+            const uint32_t d = (uint32_t)(peek_at(off) >> 37);
+            if (runs_off(off + 27)) { st |= ST_TRUNCATED; return false; }
             if (d == 0x7FFFFFFu) return false;  // empty block
-            val = peek();
-            skip(64, src);
-            if (ran_off()) { st |= ST_TRUNCATED; return false; }
+            const uint64_t v = peek_at(off + 27);
+            if (runs_off(off + 91)) { st |= ST_TRUNCATED; return false; }
+            val = v;
+            advance(off + 91, src);
             stored_delta = (int64_t)d;
             stored_ts = (uint64_t)block_ts + (uint64_t)d;
             ts_out = (int64_t)stored_ts; val_out = val;
             return true;
         }
         // ---- timestamp: leading ones of the next four bits select the bucket
-        uint32_t hi = (uint32_t)(top >> 32);
-        uint32_t ones = (uint32_t)__clz((int)~hi);  // 32 when hi is all ones
-        ones = ones > 4 ? 4 : ones;
-        int64_t dd = 0;
-        if (ones == 0) {
-            skip(1, src);
+        const uint64_t top = peek_at(off);
+        uint32_t ones = (uint32_t)__clz((int)~(uint32_t)(top >> 32));  // 32 when all ones
+        ones = ones > 4 ? 4u : ones;
+        const uint32_t plen = ones == 0 ? 0u : ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : 32u;
+        const uint32_t clen = (ones < 4 ? ones + 1u : 4u) + plen;  // 1, 9, 12, 16, 36
+        const uint32_t raw = (uint32_t)(top >> (64 - clen)) & (uint32_t)~(~0ull << plen);
+        const uint32_t o1 = off + clen;
+        const bool eos = ones == 4 && raw == 0xFFFFFFFFu;
+        int64_t dd;
+        if (FMT == FMT_V2) {
+            const uint32_t z = raw + 1u;
+            dd = (int64_t)(int32_t)((z >> 1) ^ (0u - (z & 1u)));  // decodeZigZag32
         } else {
-            uint32_t plen = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : 32u;
-            uint32_t clen = (ones < 4 ? ones + 1 : 4u) + plen;  // 9, 12, 16, 36
-            uint32_t raw = (uint32_t)(top >> (64 - clen)) & (plen == 32 ? 0xFFFFFFFFu : ((1u << plen) - 1u));
-            skip(clen, src);
-            if (ran_off()) { st |= ST_TRUNCATED; return false; }
-            if (plen == 32 && raw == 0xFFFFFFFFu) return false;  // end of stream
-            if (FMT == FMT_V2) {
-                uint32_t z = raw + 1u;
-                dd = (int64_t)(int32_t)((z >> 1) ^ (0u - (z & 1u)));  // decodeZigZag32
-            } else {
-                int64_t xr = (int64_t)raw;
-                if (plen != 32 && xr > ((int64_t)1 << (plen - 1))) xr -= ((int64_t)1 << plen);
-                dd = (int64_t)(int32_t)(uint32_t)xr;
-            }
+            int64_t xr = (int64_t)raw;
+            if (plen != 32 && xr > ((int64_t)1 << ((plen - 1) & 31))) xr -= ((int64_t)1 << plen);
+            dd = (int64_t)(int32_t)(uint32_t)xr;
         }
-        if (ran_off()) { st |= ST_TRUNCATED; return false; }
+        dd = ones ? dd : 0;
+        // ---- value header: next 14 bits
+        const uint32_t h = (uint32_t)(peek_at(o1) >> 50);
+        const bool c0 = (h >> 13) & 1u, c1 = (h >> 12) & 1u;
+        const bool fresh = c0 && c1;
+        uint32_t nlead;
+        int32_t ntrail;
+        uint32_t hlen;
+        if (FMT == FMT_V2) {
+            nlead = (h >> 6) & 63u;
+            ntrail = 64 - (int32_t)((h & 63u) + 1u) - (int32_t)nlead;
+            hlen = 14;
+        } else {
+            nlead = (h >> 7) & 31u;
+            uint32_t sig = (h >> 1) & 63u;
+            sig = sig ? sig : 64u;
+            ntrail = 64 - (int32_t)sig - (int32_t)nlead;
+            hlen = 13;
+        }
+        nlead = fresh ? nlead : lead;
+        ntrail = fresh ? ntrail : trail;
+        hlen = c0 ? (c1 ? hlen : 2u) : 1u;
+        const uint32_t o2 = o1 + hlen;
+        const bool malformed = c0 && nlead == NO_WINDOW;
+        const uint32_t n = c0 ? (uint32_t)(64 - (int32_t)nlead - ntrail) & 127u : 0u;  // 1..64 once a window exists
+        const uint64_t bits = n ? (peek_at(o2) >> ((64u - n) & 63u)) : 0ull;
+        const uint32_t o3 = o2 + (malformed ? 0u : n);
+        if (__builtin_expect(eos || malformed || runs_off(o3), 0)) {
+            // rare outcomes, in the order the reference's reads meet them
+            if (runs_off(o1)) st |= ST_TRUNCATED;
+            else if (eos) { /* end of stream */ }
+            else if (runs_off(o2)) st |= ST_TRUNCATED;
+            else if (malformed) st |= ST_MALFORMED;
+            else st |= ST_TRUNCATED;
+            return false;
+        }
+        lead = nlead;
+        trail = ntrail;
+        val ^= bits << ((uint32_t)ntrail & 63u);  // Java shifts by the count mod 64
         stored_delta = (int64_t)((uint64_t)stored_delta + (uint64_t)dd);
         stored_ts += (uint64_t)stored_delta;
-        // ---- value
-        top = peek();
-        uint32_t h = (uint32_t)(top >> 50);  // next 14 bits
-        if ((h >> 13) == 0) {
-            skip(1, src);
-        } else {
-            uint32_t hlen = 2;
-            if ((h >> 12) & 1u) {
-                if (FMT == FMT_V2) {
-                    lead = (h >> 6) & 63u;
-                    uint32_t sig = (h & 63u) + 1u;
-                    trail = 64 - (int32_t)sig - (int32_t)lead;
-                    hlen = 14;
-                } else {
-                    lead = (h >> 7) & 31u;
-                    uint32_t sig = (h >> 1) & 63u;
-                    if (sig == 0) sig = 64;
-                    trail = 64 - (int32_t)sig - (int32_t)lead;
-                    hlen = 13;
-                }
-            }
-            skip(hlen, src);
-            if (ran_off()) { st |= ST_TRUNCATED; return false; }
-            if (lead == NO_WINDOW) { st |= ST_MALFORMED; return false; }
-            uint32_t n = (uint32_t)(64 - (int32_t)lead - trail);  // 1..64 once a window exists
-            uint64_t bits = peek() >> (64 - n);
-            skip(n, src);
-            val ^= bits << ((uint32_t)trail & 63u);  // Java shifts by the count mod 64
-        }
-        if (ran_off()) { st |= ST_TRUNCATED; return false; }
+        advance(o3, src);
         ts_out = (int64_t)stored_ts; val_out = val;
         return true;
     }

@@ -12,6 +12,10 @@
 #include "codec_device.hpp"
 #include "kernels.hpp"
 
+#ifndef GTSC_ABLATE
+#define GTSC_ABLATE 0
+#endif
+
 namespace gtsc {
 
 // ------------------------------------------------------------------------
@@ -67,36 +71,42 @@ __global__ __launch_bounds__(256) void decode_direct_kernel(DecodeArgs a)
 }
 
 // ------------------------------------------------------------------------
-// Tiled form.  A wavefront owns 64 consecutive series.  Points travel between
-// HBM and the lanes through an LDS tile of 64 rows x CH points so that every
-// global access is a coalesced run of 16-byte pieces inside one series' row,
-// while each lane still consumes / produces its own series serially.
+// Tiled form.  A wavefront owns 64 consecutive series ("rows").  Points travel
+// between HBM and the lanes through LDS tiles of 64 rows x 16 points so that
+// every global access is a full, aligned 128-byte line of one row (8 lanes x
+// 16 B), while each lane still consumes / produces its own series serially.
 //
-//   HBM  --(lane l: row 16i + l/4, piece l%4, 16 B)-->  registers  --> LDS tile
+// Rows start at arbitrary point offsets, so each row gets a phase
+//     phi = (index of its first point in the array + alignment of the array) mod 16
+// and lives in "virtual slots" v = phi + point index.  Chunk c of the tile holds
+// the slots [16c, 16c+16) of every row: a chunk boundary is then a 128-byte line
+// boundary in memory for every row, whatever its length or start.  Slots outside
+// [phi, phi + npoints) are empty; only a row's first and last chunk have any.
+//
+//   HBM --(lane l: row 8i + l/8, piece l%8, 16 B)--> registers --> LDS tile
 //   LDS tile --(lane j: its own row j, piece q)--> the lane's encoder
+//   (decode runs the same path backwards)
 //
-// The tile is XOR-swizzled: piece q of row r sits at r*64 + ((q ^ ((r>>2)&3))<<4).
-// That keeps all three access shapes free of bank conflicts: the loader's
-// ds_write_b128 (8 consecutive lanes = 2 rows x 4 pieces cover 128 B), the
-// per-lane ds_read_b128 (16 lanes with distinct row%16 cover 256 B) and the
-// decoder's flush read (rows 16i + l/4).
+// The tile is XOR-swizzled: piece q of row r sits at r*128 + ((q ^ ((r>>1)&7))<<4),
+// which keeps the loader's ds_write_b128 (8 lanes = one row), the per-lane
+// ds_read_b128 (16 lanes with distinct row%16 cover 256 B) and the decoder's
+// flush reads free of bank conflicts.
 // ------------------------------------------------------------------------
-constexpr uint32_t CH = 8;                    // points per row per chunk
-constexpr uint32_t ROW_BYTES = CH * 8;        // 64
-constexpr uint32_t PIECES = ROW_BYTES / 16;   // 16-byte pieces per row
-constexpr uint32_t ROWS_PER_PASS = 64 / PIECES;
-constexpr uint32_t PASSES = 64 / ROWS_PER_PASS;
-constexpr uint32_t TILE_BYTES = 64 * ROW_BYTES;
+constexpr uint32_t CH = 16;                   // slots per row per chunk
+constexpr uint32_t ROW_BYTES = CH * 8;        // 128
+constexpr uint32_t PIECES = ROW_BYTES / 16;   // 16-byte pieces per row: 8
+constexpr uint32_t ROWS_PER_PASS = 64 / PIECES;  // 8
+constexpr uint32_t PASSES = 64 / ROWS_PER_PASS;  // 8
+constexpr uint32_t TILE_BYTES = 64 * ROW_BYTES;  // 8 KiB
 
 __device__ __forceinline__ uint32_t tile_addr(uint32_t row, uint32_t piece)
 {
-    return row * ROW_BYTES + ((piece ^ ((row >> 2) & (PIECES - 1))) << 4);
+    return row * ROW_BYTES + ((piece ^ ((row >> 1) & (PIECES - 1))) << 4);
 }
 
-struct alignas(16) U4 { uint32_t x, y, z, w; };
-struct alignas(8) U2 { uint32_t x, y; };
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));
 
-// 16-byte global access at 8-byte alignment (series rows start at any point index)
+// 16-byte global access at 8-byte alignment
 __device__ __forceinline__ U4 load16(const void* p)
 {
     U4 r;
@@ -107,6 +117,8 @@ __device__ __forceinline__ void store16(void* p, const U4& v)
 {
     __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, 16);
 }
+__device__ __forceinline__ uint64_t lo64(const U4& v) { return ((uint64_t)v.y << 32) | v.x; }
+__device__ __forceinline__ uint64_t hi64(const U4& v) { return ((uint64_t)v.w << 32) | v.z; }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
 {
@@ -118,95 +130,198 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
     return x;
 }
 
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, uint32_t src)
-{
-    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64);
-    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
+// what a loader lane needs to know about a row
+struct alignas(16) RowInfo {
+    int64_t base;  // array index of virtual slot 0 (first point index - phi)
+    uint32_t lo;   // first occupied slot (phi)
+    uint32_t hi;   // one past the last occupied slot
+};
 
+constexpr uint32_t MAX_ROW_POINTS = 0x7FFFFF00u;
+
+// Output ring of the encoder: per row RING_WORDS words, copied out in blocks of RING_BLOCK.
+// Between two flush checks (4 points) a row gains at most 4 * 114 bits = 7.2 words on top
+// of at most RING_BLOCK - 1 words that were not yet a whole block.
+constexpr uint32_t RING_WORDS = 16;
+constexpr uint32_t RING_BLOCK = 8;
+static_assert(RING_WORDS * 8 == ROW_BYTES, "ring rows share the tile geometry");
+
+#ifndef GTSC_LDS_PAD
+#define GTSC_LDS_PAD 0
+#endif
 template <int FMT>
 __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[3 * TILE_BYTES + 64 * sizeof(RowInfo) + 64 * 8 + GTSC_LDS_PAD];
     uint8_t* const tile_ts = lds;
     uint8_t* const tile_val = lds + TILE_BYTES;
+    uint8_t* const ring = lds + 2 * TILE_BYTES;  // 64 rows x RING_WORDS compressed words
+    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + 3 * TILE_BYTES);
+    uint2* const wstate = reinterpret_cast<uint2*>(lds + 3 * TILE_BYTES + 64 * sizeof(RowInfo));  // {flushed, count}
 
     const uint32_t lane = threadIdx.x;
-    const uint64_t s = (uint64_t)blockIdx.x * 64 + lane;
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t s = s0 + lane;
     const bool valid = s < a.nseries;
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t np64 = valid ? a.pts.size(s) : 0;
-    const uint32_t np = np64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)np64;
-    const uint32_t nchunks = (wave_max_u32(np) + CH - 1) / CH;
+    const uint32_t np = np64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)np64;
+    const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (CH - 1));
+    rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi + np};
+    const uint32_t nchunks = wave_max_u32(np ? (phi + np + CH - 1) / CH : 0u);
 
-    // loader role: rows this lane fetches pieces of, fixed for the whole tile
     const uint32_t piece = lane % PIECES;
-    uint64_t row_p0[PASSES];
-    uint32_t row_np[PASSES];
-#pragma unroll
-    for (uint32_t i = 0; i < PASSES; i++) {
-        const uint32_t r = i * ROWS_PER_PASS + lane / PIECES;
-        row_p0[i] = shfl_u64(p0, r);
-        row_np[i] = (uint32_t)__shfl((int)np, (int)r, 64);
-    }
+    const uint32_t lrow = lane / PIECES;  // loader role: rows lrow + 8i
     U4 rt[PASSES], rv[PASSES];
-    auto fetch = [&](uint32_t c) {
-        const uint32_t first = c * CH + 2 * piece;  // first of the two points of this piece
-#pragma unroll
-        for (uint32_t i = 0; i < PASSES; i++) {
-            const int64_t rem = (int64_t)row_np[i] - (int64_t)first;
-            const int64_t* pt = a.ts + row_p0[i] + first;
-            const uint64_t* pv = a.val + row_p0[i] + first;
-            U4 t = {0, 0, 0, 0}, v = {0, 0, 0, 0};
-            if (rem >= 2) {
-                t = load16(pt);
-                v = load16(pv);
-            } else if (rem == 1) {
-                const uint64_t t1 = (uint64_t)pt[0], v1 = pv[0];
-                t.x = (uint32_t)t1; t.y = (uint32_t)(t1 >> 32);
-                v.x = (uint32_t)v1; v.y = (uint32_t)(v1 >> 32);
-            }
-            rt[i] = t;
-            rv[i] = v;
-        }
+
+    const uint64_t cap64 = valid ? a.slots.size(s) : 0;
+    const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
+    const int64_t bts = valid ? a.block_ts[s] : 0;
+    // Completed words go to the lane's row of the ring (word w in slot w % RING_WORDS, same
+    // swizzle as the point tiles); the wavefront copies them out in whole 64-byte blocks.
+    uint32_t flushed = 0;  // words of this row already written to HBM (a multiple of RING_BLOCK)
+    auto sink = [&](uint32_t i, uint64_t w) {
+        const uint32_t sl = i & (RING_WORDS - 1);
+        *reinterpret_cast<uint64_t*>(ring + tile_addr(lane, sl >> 1) + ((sl & 1) << 3)) = w;
     };
-    auto stage = [&]() {
+    Encoder<FMT> e;
+    e.widx = 0;
+    if (valid) e.begin(bts, sink);
+
+// Copies ring words [flushed, END) of every row to its slot; END is the row's count rounded
+// down to whole blocks (FINAL == false) or the count itself.  Lane l serves row 8i + l/8,
+// ring piece l%8 (two words).  Words beyond a row's slot capacity are dropped.
+#define GTSC_FLUSH(FINAL)                                                                      \
+    {                                                                                          \
+        wstate[lane] = make_uint2(flushed, e.widx);                                            \
+        __syncthreads();                                                                       \
+        _Pragma("unroll 1") for (uint32_t i = 0; i < PASSES; i++) {                            \
+            const uint32_t r = lrow + i * ROWS_PER_PASS;                                       \
+            const uint2 ws = wstate[r];                                                        \
+            const uint32_t end = (FINAL) ? ws.y : ws.x + ((ws.y - ws.x) & ~(RING_BLOCK - 1));  \
+            const uint32_t w0 = ws.x + ((2 * piece - ws.x) & (RING_WORDS - 1));                \
+            if (w0 < end && s0 + r < a.nseries) {                                              \
+                const U4 v = *reinterpret_cast<const U4*>(ring + tile_addr(r, piece));         \
+                const uint64_t rcap = a.slots.size(s0 + r);                                    \
+                uint64_t* dst = a.out_words + a.slots.begin(s0 + r) + w0;                      \
+                if (w0 + 1 < end && w0 + 1 < rcap) store16(dst, v);                            \
+                else if (w0 < rcap) dst[0] = lo64(v);                                          \
+            }                                                                                  \
+        }                                                                                      \
+        if (!(FINAL)) flushed += (e.widx - flushed) & ~(RING_BLOCK - 1);                       \
+        __syncthreads();                                                                       \
+    }
+    __syncthreads();  // rows[] visible
+
+// loads chunk C of the tile into rt/rv (a macro: the arrays must stay in registers)
+#define GTSC_FETCH(C)                                                                          \
+    {                                                                                          \
+        const uint32_t c_ = (C);                                                               \
+        const uint32_t v0 = c_ * CH + 2 * piece; /* first of the two slots of this piece */    \
+        const bool interior = __all(c_ * CH >= phi && c_ * CH + CH <= phi + np); \
+        if (interior) {                                                                        \
+            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
+                const RowInfo ri = rows[lrow + i * ROWS_PER_PASS];                             \
+                rt[i] = load16(a.ts + (ri.base + (int64_t)v0));                                \
+                rv[i] = load16(a.val + (ri.base + (int64_t)v0));                               \
+            }                                                                                  \
+        } else {                                                                               \
+            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
+                const RowInfo ri = rows[lrow + i * ROWS_PER_PASS];                             \
+                const bool ok0 = v0 >= ri.lo && v0 < ri.hi;                                    \
+                const bool ok1 = v0 + 1 >= ri.lo && v0 + 1 < ri.hi;                            \
+                const int64_t* pt = a.ts + (ri.base + (int64_t)v0);                            \
+                const uint64_t* pv = a.val + (ri.base + (int64_t)v0);                          \
+                U4 t = {0, 0, 0, 0}, v = {0, 0, 0, 0};                                         \
+                if (ok0 && ok1) {                                                              \
+                    t = load16(pt);                                                            \
+                    v = load16(pv);                                                            \
+                } else if (ok0) {                                                              \
+                    const uint64_t t1 = (uint64_t)pt[0], v1 = pv[0];                           \
+                    t.x = (uint32_t)t1; t.y = (uint32_t)(t1 >> 32);                            \
+                    v.x = (uint32_t)v1; v.y = (uint32_t)(v1 >> 32);                            \
+                } else if (ok1) {                                                              \
+                    const uint64_t t1 = (uint64_t)pt[1], v1 = pv[1];                           \
+                    t.z = (uint32_t)t1; t.w = (uint32_t)(t1 >> 32);                            \
+                    v.z = (uint32_t)v1; v.w = (uint32_t)(v1 >> 32);                            \
+                }                                                                              \
+                rt[i] = t;                                                                     \
+                rv[i] = v;                                                                     \
+            }                                                                                  \
+        }                                                                                      \
+    }
+
+#ifdef GTSC_STAMP
+    // diagnostic build only: where a wave's cycles go (never shipped; results land in the slot tail)
+    uint64_t tk_stage = 0, tk_fetch = 0, tk_comp = 0, tk_prev = __builtin_amdgcn_s_memtime();
+#define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GTSC_TICK(acc_)
+#endif
+    if (nchunks) GTSC_FETCH(0)
+    GTSC_TICK(tk_fetch)
+    for (uint32_t c = 0; c < nchunks; c++) {
+        __syncthreads();  // every lane has read the previous chunk
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
-            const uint32_t r = i * ROWS_PER_PASS + lane / PIECES;
+            const uint32_t r = lrow + i * ROWS_PER_PASS;
             *reinterpret_cast<U4*>(tile_ts + tile_addr(r, piece)) = rt[i];
             *reinterpret_cast<U4*>(tile_val + tile_addr(r, piece)) = rv[i];
         }
-    };
-
-    uint64_t* const out = a.out_words + (valid ? a.slots.begin(s) : 0);
-    const uint64_t cap = valid ? a.slots.size(s) : 0;
-    const int64_t bts = valid ? a.block_ts[s] : 0;
-    uint32_t st = 0;
-    auto sink = [&](uint32_t i, uint64_t w) {
-        if (i < cap) out[i] = w; else st = ST_OVERFLOW;
-    };
-    Encoder<FMT> e;
-    if (nchunks) fetch(0);
-    if (valid) e.begin(bts, sink);
-    for (uint32_t c = 0; c < nchunks; c++) {
-        __syncthreads();  // every lane has read the previous chunk
-        stage();
         __syncthreads();
-        if (c + 1 < nchunks) fetch(c + 1);  // in flight while this chunk is encoded
+        GTSC_TICK(tk_stage)
+        if (c + 1 < nchunks) GTSC_FETCH(c + 1)  // in flight while this chunk is encoded
+        GTSC_TICK(tk_fetch)
+        // every lane has all 16 slots of this chunk occupied and is past its first point:
+        // no guards, no first-point test, two points per step for the scheduler to interleave
+        const bool steady = __all(c * CH >= phi && c * CH + CH <= phi + np && e.stored_ts != 0);
+        if (steady) {
 #pragma unroll 1
-        for (uint32_t q = 0; q < PIECES; q++) {
-            const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(lane, q));
-            const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
-            const uint32_t k = c * CH + 2 * q;
-            if (k < np) e.add(bts, (int64_t)(((uint64_t)t.y << 32) | t.x), ((uint64_t)v.y << 32) | v.x, sink);
-            if (k + 1 < np) e.add(bts, (int64_t)(((uint64_t)t.w << 32) | t.z), ((uint64_t)v.w << 32) | v.z, sink);
+            for (uint32_t q = 0; q < PIECES; q++) {
+                const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(lane, q));
+                const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+#if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
+                e.acc ^= lo64(t) ^ lo64(v) ^ hi64(t) ^ hi64(v);
+#else
+                e.add_next((int64_t)lo64(t), lo64(v), sink);
+                e.add_next((int64_t)hi64(t), hi64(v), sink);
+#endif
+                if ((q & 1) && __any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t q = 0; q < PIECES; q++) {
+                const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(lane, q));
+                const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                const uint32_t k = c * CH + 2 * q - phi;  // point index of the piece's first slot (wraps below phi)
+#if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
+                e.acc ^= lo64(t) ^ lo64(v) ^ hi64(t) ^ hi64(v);
+#else
+                if (k < np) e.add(bts, (int64_t)lo64(t), lo64(v), sink);
+                if (k + 1 < np) e.add(bts, (int64_t)hi64(t), hi64(v), sink);
+#endif
+                if ((q & 1) && __any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+            }
+        }
+        GTSC_TICK(tk_comp)
+    }
+#undef GTSC_FETCH
+    if (valid) e.finish(sink);
+    GTSC_FLUSH(true)
+#ifdef GTSC_STAMP
+    {
+        uint64_t tk_flush = 0;
+        GTSC_TICK(tk_flush)
+        if (lane == 0) {
+            uint64_t* dbg = a.out_words + a.slots.begin(s) + a.slots.size(s) - 4;
+            dbg[0] = tk_stage; dbg[1] = tk_fetch; dbg[2] = tk_comp; dbg[3] = tk_flush;
         }
     }
+#endif
+#undef GTSC_FLUSH
     if (valid) {
-        const uint32_t n = e.finish(sink);
-        a.out_nwords[s] = n;
+        const uint32_t st = e.widx > cap ? ST_OVERFLOW : 0u;
+        a.out_nwords[s] = e.widx;
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
     }
@@ -215,10 +330,10 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 template <int FMT>
 __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * TILE_BYTES + 64 * 4];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * TILE_BYTES + 64 * sizeof(RowInfo)];
     uint8_t* const tile_ts = lds;
     uint8_t* const tile_val = lds + TILE_BYTES;
-    uint32_t* const row_count = reinterpret_cast<uint32_t*>(lds + 2 * TILE_BYTES);
+    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + 2 * TILE_BYTES);
 
     const uint32_t lane = threadIdx.x;
     const uint64_t s = (uint64_t)blockIdx.x * 64 + lane;
@@ -228,24 +343,23 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t cap64 = valid ? a.pts.size(s) : 0;
-    const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
+    const uint32_t cap = cap64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)cap64;
+    const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (CH - 1));
+    rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi};
 
-    // flusher role: rows this lane stores pieces of
     const uint32_t piece = lane % PIECES;
-    uint64_t row_p0[PASSES];
-#pragma unroll
-    for (uint32_t i = 0; i < PASSES; i++) row_p0[i] = shfl_u64(p0, i * ROWS_PER_PASS + lane / PIECES);
+    const uint32_t lrow = lane / PIECES;
 
     auto src = [&](uint32_t i) -> uint64_t { return i < nw ? in[i] : 0ull; };
     Decoder<FMT> d;
     bool active = valid;
     if (valid) d.begin(nw, src);
-    uint32_t n = 0;       // pairs decoded
+    uint32_t n = 0;  // pairs decoded
     uint32_t st = 0;
     for (uint32_t c = 0; __any(active); c++) {
 #pragma unroll 1
         for (uint32_t k = 0; k < CH; k++) {
-            if (active) {
+            if (active && c * CH + k >= phi) {
                 int64_t t; uint64_t v;
                 if (d.next(t, v, src)) {
                     const uint32_t ad = tile_addr(lane, k >> 1) + ((k & 1) << 3);
@@ -257,24 +371,41 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
                 }
             }
         }
-        row_count[lane] = n < cap ? n : cap;  // points of this row that may be stored
+        const uint32_t stored = n < cap ? n : cap;  // points of this row that may be written out
+        rows[lane].hi = phi + stored;
+        const bool interior = __all(c * CH >= phi && c * CH + CH <= phi + stored);
         __syncthreads();
-        const uint32_t first = c * CH + 2 * piece;
+        const uint32_t v0 = c * CH + 2 * piece;
+        if (interior) {
 #pragma unroll
-        for (uint32_t i = 0; i < PASSES; i++) {
-            const uint32_t r = i * ROWS_PER_PASS + lane / PIECES;
-            const int64_t rem = (int64_t)row_count[r] - (int64_t)first;
-            if (rem >= 1) {
-                const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece));
-                const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
-                int64_t* pt = a.ts + row_p0[i] + first;
-                uint64_t* pv = a.val + row_p0[i] + first;
-                if (rem >= 2) {
-                    store16(pt, t);
-                    store16(pv, v);
-                } else {
-                    pt[0] = (int64_t)(((uint64_t)t.y << 32) | t.x);
-                    pv[0] = ((uint64_t)v.y << 32) | v.x;
+            for (uint32_t i = 0; i < PASSES; i++) {
+                const uint32_t r = lrow + i * ROWS_PER_PASS;
+                const RowInfo ri = rows[r];
+                store16(a.ts + (ri.base + (int64_t)v0), *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece)));
+                store16(a.val + (ri.base + (int64_t)v0), *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece)));
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < PASSES; i++) {
+                const uint32_t r = lrow + i * ROWS_PER_PASS;
+                const RowInfo ri = rows[r];
+                const bool ok0 = v0 >= ri.lo && v0 < ri.hi;
+                const bool ok1 = v0 + 1 >= ri.lo && v0 + 1 < ri.hi;
+                if (ok0 || ok1) {
+                    const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece));
+                    const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
+                    int64_t* pt = a.ts + (ri.base + (int64_t)v0);
+                    uint64_t* pv = a.val + (ri.base + (int64_t)v0);
+                    if (ok0 && ok1) {
+                        store16(pt, t);
+                        store16(pv, v);
+                    } else if (ok0) {
+                        pt[0] = (int64_t)lo64(t);
+                        pv[0] = lo64(v);
+                    } else {
+                        pt[1] = (int64_t)hi64(t);
+                        pv[1] = hi64(v);
+                    }
                 }
             }
         }

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgtsc.so")
+LIB_PATH = os.environ.get("GTSC_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libgtsc.so")
 
 OK, ERR_ARG, ERR_CAPACITY, ERR_HIP, ERR_STREAM = 0, -1, -2, -3, -4
 FMT_V2, FMT_V1 = 0, 1
