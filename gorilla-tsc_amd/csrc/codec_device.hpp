@@ -50,8 +50,11 @@ struct Encoder {
     uint64_t acc;
     uint32_t nacc;
     uint32_t widx;
-    uint64_t stored_ts;   // 0 = no point yet (G/GorillaCompressor.java:50,65)
-    int64_t stored_delta; // v2 keeps an int (sign-extended here), v1 a long
+    // previous timestamp: v2 does int arithmetic, so only its low half is kept; "started"
+    // stands for the reference's storedTimestamp != 0 test (G/GorillaCompressor.java:50,65)
+    uint32_t pts_lo, pts_hi;
+    bool started;
+    int64_t stored_delta;  // v2 keeps an int (sign-extended here), v1 a long
     uint64_t prev;
     uint32_t lead, trail;
 
@@ -64,7 +67,7 @@ struct Encoder {
         const uint64_t rest = (va << 1) << (63 - nacc);    // what did not fit (nacc == 0: nothing)
         const uint32_t total = nacc + n;
         const bool full = total >= 64;
-        if (full) sink(widx, word);
+        if (Sink::ALWAYS || full) sink(widx, word);  // an LDS sink takes every candidate: cheaper than a branch
         widx += full ? 1u : 0u;
         acc = full ? rest : word;
         nacc = total & 63;
@@ -74,36 +77,56 @@ struct Encoder {
     __device__ __forceinline__ void begin(int64_t block_ts, Sink& sink)
     {
         acc = 0; nacc = 0; widx = 0;
-        stored_ts = 0; stored_delta = 0; prev = 0;
+        pts_lo = 0; pts_hi = 0; started = false; stored_delta = 0; prev = 0;
         lead = NO_WINDOW; trail = 0;
         put((uint64_t)block_ts, 64, sink);  // addHeader, G/GorillaCompressor.java:39-41
+    }
+
+    // writeFirst: 27 low bits of the delta, then the raw value
+    template <class Sink>
+    __device__ __forceinline__ void first(uint64_t d, uint32_t ts_lo, uint32_t ts_hi, bool ts_zero, uint64_t v, Sink& sink)
+    {
+        stored_delta = (FMT == FMT_V2) ? (int64_t)(int32_t)(uint32_t)d : (int64_t)d;
+        pts_lo = ts_lo; pts_hi = ts_hi;
+        started = !ts_zero;
+        prev = v;
+        put(d & 0x7FFFFFFull, 27, sink);
+        put(v, 64, sink);
     }
 
     template <class Sink>
     __device__ __forceinline__ void add(int64_t block_ts, int64_t ts, uint64_t v, Sink& sink)
     {
-        if (__builtin_expect(stored_ts == 0, 0)) {
-            // writeFirst: 27 low bits of the delta, then the raw value
-            uint64_t d = (uint64_t)ts - (uint64_t)block_ts;
-            stored_delta = (FMT == FMT_V2) ? (int64_t)(int32_t)(uint32_t)d : (int64_t)d;
-            stored_ts = (uint64_t)ts;
-            prev = v;
-            put(d & 0x7FFFFFFull, 27, sink);
-            put(v, 64, sink);
+        if (__builtin_expect(!started, 0)) {
+            first((uint64_t)ts - (uint64_t)block_ts, (uint32_t)ts, (uint32_t)((uint64_t)ts >> 32), ts == 0, v, sink);
             return;
         }
-        add_next(ts, v, sink);
+        started = ts != 0;
+        add_next((uint32_t)ts, (uint32_t)((uint64_t)ts >> 32), v, sink);
     }
 
-    // A point that is known not to be a "first" point (stored_ts != 0): straight-line code.
+    // v2 only needs the low half of a timestamp plus whether the whole of it is zero
     template <class Sink>
-    __device__ __forceinline__ void add_next(int64_t ts, uint64_t v, Sink& sink)
+    __device__ __forceinline__ void add_lo(uint32_t block_ts_lo, uint32_t ts_lo, bool ts_zero, uint64_t v, Sink& sink)
+    {
+        static_assert(FMT == FMT_V2, "v1 does long arithmetic on timestamps");
+        if (__builtin_expect(!started, 0)) {
+            first((uint64_t)(ts_lo - block_ts_lo), ts_lo, 0u, ts_zero, v, sink);
+            return;
+        }
+        started = !ts_zero;
+        add_next(ts_lo, 0u, v, sink);
+    }
+
+    // A point that is known not to be a "first" point: straight-line code.
+    template <class Sink>
+    __device__ __forceinline__ void add_next(uint32_t ts_lo, uint32_t ts_hi, uint64_t v, Sink& sink)
     {
         // ---- timestamp: code (thi:tlo) of tlen bits
         uint32_t tlo, thi, tlen;
         if (FMT == FMT_V2) {
             // int arithmetic: only the low 32 bits of the timestamps take part
-            const uint32_t nd = (uint32_t)ts - (uint32_t)stored_ts;
+            const uint32_t nd = ts_lo - pts_lo;
             const int32_t dod = (int32_t)(nd - (uint32_t)(int32_t)stored_delta);
             const uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
             const uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0
@@ -115,7 +138,8 @@ struct Encoder {
             thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
             stored_delta = (int64_t)(int32_t)nd;
         } else {
-            const uint64_t nd = (uint64_t)ts - stored_ts;
+            const uint64_t ts = ((uint64_t)ts_hi << 32) | ts_lo, pts = ((uint64_t)pts_hi << 32) | pts_lo;
+            const uint64_t nd = ts - pts;
             const uint64_t dod = nd - (uint64_t)stored_delta;
             const bool zero = dod == 0;
             const bool b7 = (dod + 63u) <= 127u, b9 = (dod + 255u) <= 511u, b12 = (dod + 2047u) <= 4095u;
@@ -125,7 +149,7 @@ struct Encoder {
             thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
             stored_delta = (int64_t)nd;
         }
-        stored_ts = (uint64_t)ts;
+        pts_lo = ts_lo; pts_hi = ts_hi;
         // ---- value: header vh of vhlen bits, payload pay of plen bits
         const uint64_t x = prev ^ v;
         prev = v;

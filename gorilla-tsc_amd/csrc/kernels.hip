@@ -23,6 +23,13 @@ namespace gtsc {
 // plain global accesses.  Correct for every layout; used for tiny batches and
 // as the fallback when a series is too ragged for the tiled form.
 // ------------------------------------------------------------------------
+// word sink of the direct form: the lane's own slot in global memory
+struct GlobalSink {
+    static constexpr bool ALWAYS = false;
+    uint64_t* out; uint64_t cap; uint32_t* st;
+    __device__ __forceinline__ void operator()(uint32_t i, uint64_t w) const { if (i < cap) out[i] = w; else *st = ST_OVERFLOW; }
+};
+
 template <int FMT>
 __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
 {
@@ -33,9 +40,7 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     const uint64_t cap = a.slots.size(s);
     const int64_t bts = a.block_ts[s];
     uint32_t st = 0;
-    auto sink = [&](uint32_t i, uint64_t w) {
-        if (i < cap) out[i] = w; else st = ST_OVERFLOW;
-    };
+    GlobalSink sink{out, cap, &st};
     Encoder<FMT> e;
     e.begin(bts, sink);
     for (uint64_t i = 0; i < np; i++) e.add(bts, a.ts[p0 + i], a.val[p0 + i], sink);
@@ -144,20 +149,57 @@ constexpr uint32_t MAX_ROW_POINTS = 0x7FFFFF00u;
 // of at most RING_BLOCK - 1 words that were not yet a whole block.
 constexpr uint32_t RING_WORDS = 16;
 constexpr uint32_t RING_BLOCK = 8;
-static_assert(RING_WORDS * 8 == ROW_BYTES, "ring rows share the tile geometry");
 
 #ifndef GTSC_LDS_PAD
 #define GTSC_LDS_PAD 0
 #endif
+
+// ring rows are padded by one word so that the lanes' ds_write_b64 spread over the banks
+constexpr uint32_t RING_ROW_BYTES = RING_WORDS * 8 + 8;
+
+// word sink of the tiled form: the lane's row of the LDS ring
+struct RingSink {
+    static constexpr bool ALWAYS = true;  // a slot is simply rewritten until its word is complete
+    uint8_t* row;
+    __device__ __forceinline__ void operator()(uint32_t i, uint64_t w) const
+    {
+        *reinterpret_cast<uint64_t*>(row + ((i & (RING_WORDS - 1)) << 3)) = w;
+    }
+};
+
+// The v2 format does int arithmetic on timestamps (G/GorillaCompressor.java:74,102-103): a lane
+// only needs the low half of each timestamp, plus one bit per point telling whether the whole
+// timestamp is zero (the reference's "no point yet" test).  So the v2 timestamp tile holds 4
+// bytes per slot; v1 keeps all 8.
+template <int FMT> struct TsTile {
+    static constexpr uint32_t SLOT_BYTES = (FMT == FMT_V2) ? 4 : 8;
+    static constexpr uint32_t ROW = CH * SLOT_BYTES;      // 64 or 128 bytes
+    static constexpr uint32_t BYTES = 64 * ROW;
+    static constexpr uint32_t ROW_PIECES = ROW / 16;      // 16-byte pieces per row: 4 or 8
+    // byte address of 16-byte piece `p16` of `row`, swizzled like tile_addr()
+    __device__ static __forceinline__ uint32_t addr(uint32_t row, uint32_t p16)
+    {
+        constexpr uint32_t SH = ROW_PIECES == 4 ? 2 : 1;
+        return row * ROW + ((p16 ^ ((row >> SH) & (ROW_PIECES - 1))) << 4);
+    }
+};
+
 template <int FMT>
 __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[3 * TILE_BYTES + 64 * sizeof(RowInfo) + 64 * 8 + GTSC_LDS_PAD];
+    using TT = TsTile<FMT>;
+    constexpr uint32_t OFF_VAL = TT::BYTES;
+    constexpr uint32_t OFF_RING = OFF_VAL + TILE_BYTES;
+    constexpr uint32_t OFF_ROWS = OFF_RING + 64 * RING_ROW_BYTES;
+    constexpr uint32_t OFF_WSTATE = OFF_ROWS + 64 * sizeof(RowInfo);
+    constexpr uint32_t OFF_ZERO = OFF_WSTATE + 64 * 8;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ZERO + 64 * 4 + GTSC_LDS_PAD];
     uint8_t* const tile_ts = lds;
-    uint8_t* const tile_val = lds + TILE_BYTES;
-    uint8_t* const ring = lds + 2 * TILE_BYTES;  // 64 rows x RING_WORDS compressed words
-    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + 3 * TILE_BYTES);
-    uint2* const wstate = reinterpret_cast<uint2*>(lds + 3 * TILE_BYTES + 64 * sizeof(RowInfo));  // {flushed, count}
+    uint8_t* const tile_val = lds + OFF_VAL;
+    uint8_t* const ring = lds + OFF_RING;  // 64 rows x RING_WORDS compressed words
+    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + OFF_ROWS);
+    uint2* const wstate = reinterpret_cast<uint2*>(lds + OFF_WSTATE);  // {flushed, count}
+    uint32_t* const rowzero = reinterpret_cast<uint32_t*>(lds + OFF_ZERO);  // v2: bit k = slot k's timestamp is 0
 
     const uint32_t lane = threadIdx.x;
     const uint64_t s0 = (uint64_t)blockIdx.x * 64;
@@ -168,29 +210,28 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
     const uint32_t np = np64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)np64;
     const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (CH - 1));
     rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi + np};
+    rowzero[lane] = 0;
     const uint32_t nchunks = wave_max_u32(np ? (phi + np + CH - 1) / CH : 0u);
 
     const uint32_t piece = lane % PIECES;
-    const uint32_t lrow = lane / PIECES;  // loader role: rows lrow + 8i
-    U4 rt[PASSES], rv[PASSES];
+    const uint32_t lrow = lane / PIECES;  // loader / flusher role: rows lrow + 8i
+    U4 rt[PASSES] = {}, rv[PASSES] = {};
 
     const uint64_t cap64 = valid ? a.slots.size(s) : 0;
     const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
     const int64_t bts = valid ? a.block_ts[s] : 0;
-    // Completed words go to the lane's row of the ring (word w in slot w % RING_WORDS, same
-    // swizzle as the point tiles); the wavefront copies them out in whole 64-byte blocks.
+    // Completed words go to the lane's row of the ring (word w in slot w % RING_WORDS); the
+    // wavefront copies them out in whole 64-byte blocks.
     uint32_t flushed = 0;  // words of this row already written to HBM (a multiple of RING_BLOCK)
-    auto sink = [&](uint32_t i, uint64_t w) {
-        const uint32_t sl = i & (RING_WORDS - 1);
-        *reinterpret_cast<uint64_t*>(ring + tile_addr(lane, sl >> 1) + ((sl & 1) << 3)) = w;
-    };
+    RingSink sink{ring + lane * RING_ROW_BYTES};
     Encoder<FMT> e;
     e.widx = 0;
+    e.started = false;
     if (valid) e.begin(bts, sink);
 
 // Copies ring words [flushed, END) of every row to its slot; END is the row's count rounded
 // down to whole blocks (FINAL == false) or the count itself.  Lane l serves row 8i + l/8,
-// ring piece l%8 (two words).  Words beyond a row's slot capacity are dropped.
+// ring slots 2*(l%8) and the next.  Words beyond a row's slot capacity are dropped.
 #define GTSC_FLUSH(FINAL)                                                                      \
     {                                                                                          \
         wstate[lane] = make_uint2(flushed, e.widx);                                            \
@@ -201,52 +242,39 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
             const uint32_t end = (FINAL) ? ws.y : ws.x + ((ws.y - ws.x) & ~(RING_BLOCK - 1));  \
             const uint32_t w0 = ws.x + ((2 * piece - ws.x) & (RING_WORDS - 1));                \
             if (w0 < end && s0 + r < a.nseries) {                                              \
-                const U4 v = *reinterpret_cast<const U4*>(ring + tile_addr(r, piece));         \
+                const uint64_t* src = reinterpret_cast<const uint64_t*>(ring + r * RING_ROW_BYTES + piece * 16); \
+                const uint64_t x0 = src[0], x1 = src[1];                                       \
                 const uint64_t rcap = a.slots.size(s0 + r);                                    \
                 uint64_t* dst = a.out_words + a.slots.begin(s0 + r) + w0;                      \
-                if (w0 + 1 < end && w0 + 1 < rcap) store16(dst, v);                            \
-                else if (w0 < rcap) dst[0] = lo64(v);                                          \
+                if (w0 + 1 < end && w0 + 1 < rcap) {                                           \
+                    const U4 v = {(uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32)}; \
+                    store16(dst, v);                                                           \
+                } else if (w0 < rcap) {                                                        \
+                    dst[0] = x0;                                                               \
+                }                                                                              \
             }                                                                                  \
         }                                                                                      \
         if (!(FINAL)) flushed += (e.widx - flushed) & ~(RING_BLOCK - 1);                       \
         __syncthreads();                                                                       \
     }
-    __syncthreads();  // rows[] visible
 
-// loads chunk C of the tile into rt/rv (a macro: the arrays must stay in registers)
+// Loads chunk C of the tile into rt/rv (a macro: the arrays must stay in registers).  A piece
+// is fetched whole when either of its two slots is occupied: pieces are 16-byte aligned in
+// memory, so the access stays inside a page that holds a valid point, and the lanes never
+// look at slots outside [phi, phi + npoints).  There is deliberately one code path with a
+// single-armed `if`: diverging paths that both define the quads make the register allocator
+// copy them where the paths join, which waits for the loads on the spot.
 #define GTSC_FETCH(C)                                                                          \
     {                                                                                          \
-        const uint32_t c_ = (C);                                                               \
-        const uint32_t v0 = c_ * CH + 2 * piece; /* first of the two slots of this piece */    \
-        const bool interior = __all(c_ * CH >= phi && c_ * CH + CH <= phi + np); \
-        if (interior) {                                                                        \
-            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
-                const RowInfo ri = rows[lrow + i * ROWS_PER_PASS];                             \
-                rt[i] = load16(a.ts + (ri.base + (int64_t)v0));                                \
-                rv[i] = load16(a.val + (ri.base + (int64_t)v0));                               \
-            }                                                                                  \
-        } else {                                                                               \
-            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
-                const RowInfo ri = rows[lrow + i * ROWS_PER_PASS];                             \
-                const bool ok0 = v0 >= ri.lo && v0 < ri.hi;                                    \
-                const bool ok1 = v0 + 1 >= ri.lo && v0 + 1 < ri.hi;                            \
-                const int64_t* pt = a.ts + (ri.base + (int64_t)v0);                            \
-                const uint64_t* pv = a.val + (ri.base + (int64_t)v0);                          \
-                U4 t = {0, 0, 0, 0}, v = {0, 0, 0, 0};                                         \
-                if (ok0 && ok1) {                                                              \
-                    t = load16(pt);                                                            \
-                    v = load16(pv);                                                            \
-                } else if (ok0) {                                                              \
-                    const uint64_t t1 = (uint64_t)pt[0], v1 = pv[0];                           \
-                    t.x = (uint32_t)t1; t.y = (uint32_t)(t1 >> 32);                            \
-                    v.x = (uint32_t)v1; v.y = (uint32_t)(v1 >> 32);                            \
-                } else if (ok1) {                                                              \
-                    const uint64_t t1 = (uint64_t)pt[1], v1 = pv[1];                           \
-                    t.z = (uint32_t)t1; t.w = (uint32_t)(t1 >> 32);                            \
-                    v.z = (uint32_t)v1; v.w = (uint32_t)(v1 >> 32);                            \
-                }                                                                              \
-                rt[i] = t;                                                                     \
-                rv[i] = v;                                                                     \
+        const uint32_t v0 = (C) * CH + 2 * piece; /* first of the two slots of this piece */   \
+        U4 ri_[PASSES]; /* RowInfo as one 16-byte LDS read each, all issued before any is used */ \
+        _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++)                                \
+            ri_[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);            \
+        _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
+            const int64_t idx = (int64_t)(((uint64_t)ri_[i].y << 32) | ri_[i].x) + (int64_t)v0; \
+            if ((v0 + 1 >= ri_[i].z) & (v0 < ri_[i].w)) {                                      \
+                rt[i] = load16(a.ts + idx);                                                    \
+                rv[i] = load16(a.val + idx);                                                   \
             }                                                                                  \
         }                                                                                      \
     }
@@ -258,6 +286,7 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 #else
 #define GTSC_TICK(acc_)
 #endif
+    __syncthreads();  // rows[] visible
     if (nchunks) GTSC_FETCH(0)
     GTSC_TICK(tk_fetch)
     for (uint32_t c = 0; c < nchunks; c++) {
@@ -265,41 +294,72 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
-            *reinterpret_cast<U4*>(tile_ts + tile_addr(r, piece)) = rt[i];
+            // Opaque to the optimiser: otherwise the element picks below are folded into the
+            // branches that loaded the quads and the wave waits for each load where it is issued.
+            asm volatile("" : "+v"(rt[i]), "+v"(rv[i]));
+            if constexpr (FMT == FMT_V2) {
+                // low halves of the piece's two timestamps: 8 bytes at slot 2*piece of the row
+                // (two dword stores: ds_write2_b32 takes them from wherever the load left them)
+                uint32_t* const dst = reinterpret_cast<uint32_t*>(tile_ts + TT::addr(r, piece >> 1) + ((piece & 1) << 3));
+                dst[0] = rt[i].x;
+                dst[1] = rt[i].z;
+                const uint32_t zb = ((rt[i].x | rt[i].y) == 0 ? 1u : 0u) | ((rt[i].z | rt[i].w) == 0 ? 2u : 0u);
+                if (zb) atomicOr(&rowzero[r], zb << (2 * piece));
+            } else {
+                *reinterpret_cast<U4*>(tile_ts + TT::addr(r, piece)) = rt[i];
+            }
             *reinterpret_cast<U4*>(tile_val + tile_addr(r, piece)) = rv[i];
         }
         __syncthreads();
         GTSC_TICK(tk_stage)
         if (c + 1 < nchunks) GTSC_FETCH(c + 1)  // in flight while this chunk is encoded
         GTSC_TICK(tk_fetch)
-        // every lane has all 16 slots of this chunk occupied and is past its first point:
-        // no guards, no first-point test, two points per step for the scheduler to interleave
-        const bool steady = __all(c * CH >= phi && c * CH + CH <= phi + np && e.stored_ts != 0);
-        if (steady) {
+        const bool interior = c * CH >= phi && c * CH + CH <= phi + np;
+        if constexpr (FMT == FMT_V2) {
+            const uint32_t zbits = rowzero[lane];
+            if (__builtin_expect(zbits != 0, 0)) rowzero[lane] = 0;
+            const uint32_t bts_lo = (uint32_t)bts;
+            // every lane has all 16 slots occupied, is past its first point and sees no zero
+            // timestamp: no guards, no first-point test, four points per step
+            if (__all(interior && e.started && zbits == 0)) {
 #pragma unroll 1
-            for (uint32_t q = 0; q < PIECES; q++) {
-                const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(lane, q));
-                const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                for (uint32_t q = 0; q < PIECES; q += 2) {
+                    const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
+                    const U4 va = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                    const U4 vb = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q + 1));
 #if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
-                e.acc ^= lo64(t) ^ lo64(v) ^ hi64(t) ^ hi64(v);
+                    e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
 #else
-                e.add_next((int64_t)lo64(t), lo64(v), sink);
-                e.add_next((int64_t)hi64(t), hi64(v), sink);
+                    e.add_next(tl.x, 0u, lo64(va), sink);
+                    e.add_next(tl.y, 0u, hi64(va), sink);
+                    e.add_next(tl.z, 0u, lo64(vb), sink);
+                    e.add_next(tl.w, 0u, hi64(vb), sink);
 #endif
-                if ((q & 1) && __any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+                    if (__any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+                }
+            } else {
+#pragma unroll 1
+                for (uint32_t q = 0; q < PIECES; q += 2) {
+                    const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
+                    const U4 va = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                    const U4 vb = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q + 1));
+                    const uint32_t k = c * CH + 2 * q - phi;  // point index of slot 2q (wraps below phi)
+                    const uint32_t zq = zbits >> (2 * q);
+                    if (k < np) e.add_lo(bts_lo, tl.x, zq & 1u, lo64(va), sink);
+                    if (k + 1 < np) e.add_lo(bts_lo, tl.y, (zq >> 1) & 1u, hi64(va), sink);
+                    if (k + 2 < np) e.add_lo(bts_lo, tl.z, (zq >> 2) & 1u, lo64(vb), sink);
+                    if (k + 3 < np) e.add_lo(bts_lo, tl.w, (zq >> 3) & 1u, hi64(vb), sink);
+                    if (__any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+                }
             }
         } else {
 #pragma unroll 1
             for (uint32_t q = 0; q < PIECES; q++) {
-                const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(lane, q));
+                const U4 t = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q));
                 const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
-                const uint32_t k = c * CH + 2 * q - phi;  // point index of the piece's first slot (wraps below phi)
-#if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
-                e.acc ^= lo64(t) ^ lo64(v) ^ hi64(t) ^ hi64(v);
-#else
+                const uint32_t k = c * CH + 2 * q - phi;
                 if (k < np) e.add(bts, (int64_t)lo64(t), lo64(v), sink);
                 if (k + 1 < np) e.add(bts, (int64_t)hi64(t), hi64(v), sink);
-#endif
                 if ((q & 1) && __any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
             }
         }
