@@ -329,4 +329,150 @@ struct Decoder {
     }
 };
 
+// ---------------------------------------------------------------- window decoder
+// The same parser over an explicit three-word window: the caller supplies the image
+// words widx..widx+2 (from an LDS ring) before every point and takes back the new
+// position.  A point spans at most 63 + 114 bits, so three words always suffice.
+template <int FMT>
+struct WindowDecoder {
+    uint32_t widx, off, nwords;  // word index of w0, bit offset inside it, image length
+    uint32_t st;
+    int64_t block_ts, stored_delta;
+    uint64_t stored_ts, val;
+    uint32_t lead;
+    int32_t trail;
+
+    // true when a field ending o bits into the window runs off the image (the reader's
+    // eager load of the following word, G/LongArrayInput.java:48-52)
+    __device__ __forceinline__ bool runs_off(uint32_t o) const { return widx + (o >> 6) >= nwords; }
+    __device__ __forceinline__ void advance(uint32_t o) { widx += o >> 6; off = o & 63; }
+
+    // header word: w0 is word 0 of the image
+    __device__ __forceinline__ void begin(uint32_t nwords_, uint64_t w0)
+    {
+        nwords = nwords_;
+        widx = 0; off = 0;
+        stored_ts = 0; stored_delta = 0; val = 0;
+        lead = NO_WINDOW; trail = 0;
+        block_ts = (int64_t)w0;
+        st = runs_off(64) ? ST_TRUNCATED : 0u;  // also covers nwords == 0
+        advance(64);
+    }
+
+    // What one ordinary (not first) point parses to, before anything is committed.
+    struct Parsed {
+        uint32_t o1, o2, o3;  // window offsets after the timestamp code, the value header, the payload
+        uint32_t lead;
+        int32_t trail;
+        uint64_t bits;        // payload, right-aligned
+        int64_t dd;           // delta of delta
+        bool eos, malformed;
+    };
+
+    // Branch-free parse of an ordinary point from 128 bits of stream (hi,lo) at the current position.
+    __device__ __forceinline__ Parsed parse(uint64_t hi, uint64_t lo) const
+    {
+        Parsed p;
+        // ---- timestamp: leading ones of the next four bits select the bucket
+        const uint32_t top = (uint32_t)(hi >> 32);
+        uint32_t ones = (uint32_t)__clz((int)~top);  // 32 when all ones
+        ones = ones > 4 ? 4u : ones;
+        // payload width 0, 7, 9, 12, 32 and code length 1, 9, 12, 16, 36
+        const uint32_t plen = ones == 4 ? 32u : ((0x0C090700u >> (8 * ones)) & 0xFFu);
+        const uint32_t clen = plen + (ones < 4 ? ones + 1u : 4u);
+        const uint32_t raw = (uint32_t)(hi >> (64 - clen)) & (uint32_t)~(~0ull << plen);
+        p.eos = ones == 4 && raw == 0xFFFFFFFFu;
+        int64_t dd;
+        if (FMT == FMT_V2) {
+            const uint32_t z = raw + 1u;
+            dd = (int64_t)(int32_t)((z >> 1) ^ (0u - (z & 1u)));  // decodeZigZag32
+        } else {
+            // two's complement payloads; exactly 2^(n-1) stays positive (G/Decompressor.java:98-100)
+            const uint32_t half = 1u << ((plen - 1) & 31);
+            const uint32_t ext = (plen != 32 && raw > half) ? raw - (half << 1) : raw;
+            dd = (int64_t)(int32_t)ext;
+        }
+        p.dd = ones ? dd : 0;
+        // ---- value header: the 14 bits after the timestamp code (clen + 14 <= 50)
+        const uint32_t h = (uint32_t)((hi << clen) >> 50);
+        const bool c0 = (h >> 13) & 1u, c1 = (h >> 12) & 1u;
+        const bool fresh = c0 && c1;
+        uint32_t nlead, hlen;
+        int32_t ntrail;
+        if (FMT == FMT_V2) {
+            nlead = (h >> 6) & 63u;
+            ntrail = 63 - (int32_t)(h & 63u) - (int32_t)nlead;
+            hlen = 14;
+        } else {
+            nlead = (h >> 7) & 31u;
+            uint32_t sig = (h >> 1) & 63u;
+            sig = sig ? sig : 64u;
+            ntrail = 64 - (int32_t)sig - (int32_t)nlead;
+            hlen = 13;
+        }
+        p.lead = fresh ? nlead : lead;
+        p.trail = fresh ? ntrail : trail;
+        hlen = c0 ? (c1 ? hlen : 2u) : 1u;
+        const uint32_t p2 = clen + hlen;  // <= 50: start of the payload inside (hi,lo)
+        p.malformed = c0 && p.lead == NO_WINDOW;
+        const uint32_t n = c0 ? (uint32_t)(64 - (int32_t)p.lead - p.trail) & 127u : 0u;  // 1..64 once a window exists
+        const uint64_t pay = (hi << p2) | ((lo >> 1) >> (63 - p2));
+        p.bits = n ? (pay >> ((64u - n) & 63u)) : 0ull;
+        p.o1 = off + clen;
+        p.o2 = off + p2;
+        p.o3 = p.o2 + (p.malformed ? 0u : n);
+        return p;
+    }
+    __device__ __forceinline__ bool rare(const Parsed& p) const { return p.eos || p.malformed || runs_off(p.o3); }
+    __device__ __forceinline__ void commit(const Parsed& p)
+    {
+        lead = p.lead;
+        trail = p.trail;
+        val ^= p.bits << ((uint32_t)p.trail & 63u);  // Java shifts by the count mod 64
+        stored_delta = (int64_t)((uint64_t)stored_delta + (uint64_t)p.dd);
+        stored_ts += (uint64_t)stored_delta;
+        advance(p.o3);
+    }
+    __device__ __forceinline__ static void window(uint64_t w0, uint64_t w1, uint64_t w2, uint32_t off, uint64_t& hi, uint64_t& lo)
+    {
+        hi = (w0 << off) | ((w1 >> 1) >> (63 - off));
+        lo = (w1 << off) | ((w2 >> 1) >> (63 - off));
+    }
+
+    // Decodes the next pair from the window (w0,w1,w2 = words widx..widx+2).
+    // Returns true when a pair was produced; false at end of stream or on error (st != 0).
+    __device__ __forceinline__ bool next(uint64_t w0, uint64_t w1, uint64_t w2, int64_t& ts_out, uint64_t& val_out)
+    {
+        if (st) return false;
+        uint64_t hi, lo;
+        window(w0, w1, w2, off, hi, lo);
+        if (__builtin_expect(stored_ts == 0, 0)) {
+            // first(): 27-bit delta, 64-bit value
+            const uint32_t d = (uint32_t)(hi >> 37);
+            if (runs_off(off + 27)) { st |= ST_TRUNCATED; return false; }
+            if (d == 0x7FFFFFFu) return false;  // empty block
+            if (runs_off(off + 91)) { st |= ST_TRUNCATED; return false; }
+            val = (hi << 27) | (lo >> 37);
+            advance(off + 91);
+            stored_delta = (int64_t)d;
+            stored_ts = (uint64_t)block_ts + (uint64_t)d;
+            ts_out = (int64_t)stored_ts; val_out = val;
+            return true;
+        }
+        const Parsed p = parse(hi, lo);
+        if (__builtin_expect(rare(p), 0)) {
+            // rare outcomes, in the order the reference's reads meet them
+            if (runs_off(p.o1)) st |= ST_TRUNCATED;
+            else if (p.eos) { /* end of stream */ }
+            else if (runs_off(p.o2)) st |= ST_TRUNCATED;
+            else if (p.malformed) st |= ST_MALFORMED;
+            else st |= ST_TRUNCATED;
+            return false;
+        }
+        commit(p);
+        ts_out = (int64_t)stored_ts; val_out = val;
+        return true;
+    }
+};
+
 }  // namespace gtsc

@@ -111,6 +111,17 @@ __device__ __forceinline__ uint32_t tile_addr(uint32_t row, uint32_t piece)
 
 typedef uint32_t U4 __attribute__((ext_vector_type(4)));
 
+// The tiled kernels run one wavefront per workgroup.  The LDS executes a wavefront's
+// instructions in order, so lanes exchanging data through LDS need no hardware wait, only
+// that the compiler keeps the accesses in program order.  (__syncthreads() would also wait
+// for every outstanding global store, which costs a memory round trip per tile flush.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // 16-byte global access at 8-byte alignment
 __device__ __forceinline__ U4 load16(const void* p)
 {
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 #define GTSC_FLUSH(FINAL)                                                                      \
     {                                                                                          \
         wstate[lane] = make_uint2(flushed, e.widx);                                            \
-        __syncthreads();                                                                       \
+        wave_sync();                                                                       \
         _Pragma("unroll 1") for (uint32_t i = 0; i < PASSES; i++) {                            \
             const uint32_t r = lrow + i * ROWS_PER_PASS;                                       \
             const uint2 ws = wstate[r];                                                        \
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
             }                                                                                  \
         }                                                                                      \
         if (!(FINAL)) flushed += (e.widx - flushed) & ~(RING_BLOCK - 1);                       \
-        __syncthreads();                                                                       \
+        wave_sync();                                                                       \
     }
 
 // Loads chunk C of the tile into rt/rv (a macro: the arrays must stay in registers).  A piece
@@ -286,11 +297,11 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
 #else
 #define GTSC_TICK(acc_)
 #endif
-    __syncthreads();  // rows[] visible
+    wave_sync();  // rows[] visible
     if (nchunks) GTSC_FETCH(0)
     GTSC_TICK(tk_fetch)
     for (uint32_t c = 0; c < nchunks; c++) {
-        __syncthreads();  // every lane has read the previous chunk
+        wave_sync();  // every lane has read the previous chunk
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
             }
             *reinterpret_cast<U4*>(tile_val + tile_addr(r, piece)) = rv[i];
         }
-        __syncthreads();
+        wave_sync();
         GTSC_TICK(tk_stage)
         if (c + 1 < nchunks) GTSC_FETCH(c + 1)  // in flight while this chunk is encoded
         GTSC_TICK(tk_fetch)
@@ -387,42 +398,172 @@ __global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
     }
 }
 
+// Decoder geometry.  Output tiles hold 16 slots per row like the encoder's: stores of whole
+// 128-byte lines run about 1.5x faster than 64-byte half lines.  The compressed words reach
+// the lanes through a per-row LDS ring of 16 words.  It is filled with one 128-byte read per
+// row at the start and then topped up in 32-byte blocks whose loads are issued at one check
+// and written to the ring at the next, so their latency hides behind two points of decoding.
+//   check every 2 points; a row is topped up while it holds <= 12 unread words:
+//   it held >= 13 at the previous check and two points consume <= 4, so >= 9 at issue,
+//   >= 5 when the block lands (a point needs 3), and <= 12 + 4 = 16 = capacity after it.
+constexpr uint32_t DCH = CH;                      // slots per row per chunk
+constexpr uint32_t IN_RING_WORDS = 16;            // ring capacity per row
+constexpr uint32_t IN_RING_BLOCK = 4;             // top-up granule (32 bytes)
+constexpr uint32_t IN_RING_LOW = 12;              // top up while unread words <= this
+constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 2) * 8;  // + mirror of slots 0 and 1: a 3-word window never wraps
+constexpr uint32_t IN_DONE = 0xFFFFFF00u;         // "filled" value of a row whose image is fully loaded
+constexpr uint32_t IN_LPR = IN_RING_BLOCK / 2;    // loader lanes per row (two words each)
+constexpr uint32_t IN_ROWS_PER_PASS = 64 / IN_LPR;
+constexpr uint32_t IN_PASSES = 64 / IN_ROWS_PER_PASS;
+
 template <int FMT>
 __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * TILE_BYTES + 64 * sizeof(RowInfo)];
+    constexpr uint32_t OFF_VAL = TILE_BYTES;
+    constexpr uint32_t OFF_RING = 2 * TILE_BYTES;
+    constexpr uint32_t OFF_ROWS = OFF_RING + 64 * IN_RING_ROW_BYTES;
+    constexpr uint32_t OFF_FILL = OFF_ROWS + 64 * sizeof(RowInfo);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_FILL + 64 * 8];
     uint8_t* const tile_ts = lds;
-    uint8_t* const tile_val = lds + TILE_BYTES;
-    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + 2 * TILE_BYTES);
+    uint8_t* const tile_val = lds + OFF_VAL;
+    uint8_t* const ring = lds + OFF_RING;
+    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + OFF_ROWS);
+    uint2* const fill = reinterpret_cast<uint2*>(lds + OFF_FILL);  // {words loaded so far, image length}
 
     const uint32_t lane = threadIdx.x;
-    const uint64_t s = (uint64_t)blockIdx.x * 64 + lane;
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t s = s0 + lane;
     const bool valid = s < a.nseries;
-    const uint64_t* in = a.words + (valid ? a.slots.begin(s) : 0);
     uint64_t nw64 = valid ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t cap64 = valid ? a.pts.size(s) : 0;
     const uint32_t cap = cap64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)cap64;
-    const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (CH - 1));
+    const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (DCH - 1));
     rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi};
+    uint32_t filled = nw ? 0u : IN_DONE;  // this row's ring holds image words [.., filled)
+    fill[lane] = make_uint2(filled, nw);
 
     const uint32_t piece = lane % PIECES;
-    const uint32_t lrow = lane / PIECES;
+    const uint32_t lrow = lane / PIECES;  // loader / flusher role: rows lrow + 16i
+    const uint8_t* const my_ring = ring + lane * IN_RING_ROW_BYTES;
 
-    auto src = [&](uint32_t i) -> uint64_t { return i < nw ? in[i] : 0ull; };
-    Decoder<FMT> d;
+    WindowDecoder<FMT> d;
+    d.widx = 0; d.off = 0; d.st = 0;
     bool active = valid;
-    if (valid) d.begin(nw, src);
+
+    // ---- initial fill: words 0..15 of every image, 8 lanes x 16 bytes per row; all loads are
+    // issued before any is used (an image's last odd word comes as the upper half of the 16
+    // bytes before it, so there is a single load per pass)
+    {
+        U4 q[PASSES];
+        wave_sync();
+#pragma unroll
+        for (uint32_t i = 0; i < PASSES; i++) {
+            const uint32_t r = lrow + i * ROWS_PER_PASS;
+            const uint32_t rnw = fill[r].y, w = 2 * piece;
+            const uint32_t back = (w + 1 < rnw) ? 0u : 1u;
+            q[i] = U4{0, 0, 0, 0};
+            if (w < rnw && rnw >= 2) q[i] = load16(a.words + a.slots.begin(s0 + r) + (w - back));
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < PASSES; i++) {
+            const uint32_t r = lrow + i * ROWS_PER_PASS;
+            asm volatile("" : "+v"(q[i]));
+            const uint32_t rnw = fill[r].y, w = 2 * piece;
+            const bool upper = !(w + 1 < rnw) && w < rnw;
+            const uint64_t x0 = upper ? hi64(q[i]) : lo64(q[i]);
+            const uint64_t x1 = upper ? 0ull : hi64(q[i]);
+            uint64_t* dst = reinterpret_cast<uint64_t*>(ring + r * IN_RING_ROW_BYTES) + w;
+            dst[0] = x0; dst[1] = x1;
+            if (piece == 0) { dst[IN_RING_WORDS] = x0; dst[IN_RING_WORDS + 1] = x1; }
+        }
+        filled = (nw <= IN_RING_WORDS) ? IN_DONE : IN_RING_WORDS;
+        wave_sync();
+    }
+    if (valid) d.begin(nw, *reinterpret_cast<const uint64_t*>(my_ring));
+
+    // ---- top-up state: loads in flight between two checks
+    bool pending = false;       // wave-uniform: a top-up has been issued and not yet landed
+    bool mine = false;          // this lane's row is part of it
+    U4 tq[IN_PASSES];           // what this lane loaded for rows lane/2 + 32i
+    uint32_t tw[IN_PASSES];     // ring slot it goes to, bit 31 = use the upper half only, all ones = nothing
+#pragma unroll
+    for (uint32_t i = 0; i < IN_PASSES; i++) { tq[i] = U4{0, 0, 0, 0}; tw[i] = 0xFFFFFFFFu; }
+
+#define GTSC_TOPUP_LAND()                                                                      \
+    {                                                                                          \
+        _Pragma("unroll") for (uint32_t i = 0; i < IN_PASSES; i++) {                           \
+            if (tw[i] != 0xFFFFFFFFu) {                                                        \
+                asm volatile("" : "+v"(tq[i]));                                                \
+                const uint32_t r = lane / IN_LPR + i * IN_ROWS_PER_PASS;                       \
+                const bool upper = tw[i] >> 31;                                                \
+                const uint64_t x0 = upper ? hi64(tq[i]) : lo64(tq[i]);                         \
+                const uint64_t x1 = upper ? 0ull : hi64(tq[i]);                                \
+                const uint32_t sl = tw[i] & (IN_RING_WORDS - 1);                               \
+                uint64_t* dst = reinterpret_cast<uint64_t*>(ring + r * IN_RING_ROW_BYTES) + sl; \
+                dst[0] = x0; dst[1] = x1;                                                      \
+                if (sl == 0) { dst[IN_RING_WORDS] = x0; dst[IN_RING_WORDS + 1] = x1; }         \
+            }                                                                                  \
+        }                                                                                      \
+        if (mine) { filled += IN_RING_BLOCK; if (filled >= nw) filled = IN_DONE; }             \
+        pending = false;                                                                       \
+        wave_sync();                                                                           \
+    }
+// Lane l serves row 32i + l/2, words 2*(l%2) and the next of the row's next block.  One load
+// instruction per pass whatever the case (an image's last odd word is fetched as the upper
+// half of the 16 bytes before it), so that nothing waits for the data here.
+#define GTSC_TOPUP_ISSUE(NEED)                                                                 \
+    {                                                                                          \
+        mine = (NEED);                                                                         \
+        fill[lane].x = mine ? filled : 0xFFFFFFFFu; /* all ones: nothing to do for this row */ \
+        wave_sync();                                                                           \
+        _Pragma("unroll") for (uint32_t i = 0; i < IN_PASSES; i++) {                           \
+            const uint32_t r = lane / IN_LPR + i * IN_ROWS_PER_PASS;                           \
+            const uint2 f = fill[r];                                                           \
+            const uint32_t w = f.x + 2 * (lane % IN_LPR); /* image word index */               \
+            const bool ok = f.x != 0xFFFFFFFFu && w < f.y;                                     \
+            const uint32_t back = (w + 1 < f.y) ? 0u : 1u;                                     \
+            tw[i] = ok ? ((w & (IN_RING_WORDS - 1)) | (back << 31)) : 0xFFFFFFFFu;             \
+            if (ok) tq[i] = load16(a.words + a.slots.begin(s0 + r) + (w - back));              \
+        }                                                                                      \
+        pending = true;                                                                        \
+        wave_sync();                                                                           \
+    }
+
     uint32_t n = 0;  // pairs decoded
     uint32_t st = 0;
+#ifdef GTSC_STAMP
+    uint64_t tk_comp = 0, tk_flush = 0, tk_prev = __builtin_amdgcn_s_memtime();
+#define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GTSC_TICK(acc_)
+#endif
     for (uint32_t c = 0; __any(active); c++) {
 #pragma unroll 1
-        for (uint32_t k = 0; k < CH; k++) {
-            if (active && c * CH + k >= phi) {
+        for (uint32_t k = 0; k < DCH; k++) {
+            const bool go = active && c * DCH + k >= phi;
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1));
+            const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t ad = tile_addr(lane, k >> 1) + ((k & 1) << 3);
+            bool done = false;
+            if (__all(go && d.stored_ts != 0)) {
+                // every lane is at an ordinary point: parse without any per-lane control flow and
+                // commit wholesale unless some lane met the end of its stream or an error
+                uint64_t hi, lo;
+                WindowDecoder<FMT>::window(w0, w1, w2, d.off, hi, lo);
+                const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);
+                if (!__any(d.rare(p))) {
+                    d.commit(p);
+                    *reinterpret_cast<uint64_t*>(tile_ts + ad) = d.stored_ts;
+                    *reinterpret_cast<uint64_t*>(tile_val + ad) = d.val;
+                    n++;
+                    done = true;
+                }
+            }
+            if (!done && go) {
                 int64_t t; uint64_t v;
-                if (d.next(t, v, src)) {
-                    const uint32_t ad = tile_addr(lane, k >> 1) + ((k & 1) << 3);
+                if (d.next(w0, w1, w2, t, v)) {
                     *reinterpret_cast<uint64_t*>(tile_ts + ad) = (uint64_t)t;
                     *reinterpret_cast<uint64_t*>(tile_val + ad) = v;
                     n++;
@@ -430,47 +571,67 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
                     active = false;
                 }
             }
+            if (k & 1) {
+                if (pending) GTSC_TOPUP_LAND()
+                const bool low = active && filled != IN_DONE && filled - d.widx <= IN_RING_LOW;
+                if (__any(low)) GTSC_TOPUP_ISSUE(low)
+            }
         }
+        GTSC_TICK(tk_comp)
         const uint32_t stored = n < cap ? n : cap;  // points of this row that may be written out
         rows[lane].hi = phi + stored;
-        const bool interior = __all(c * CH >= phi && c * CH + CH <= phi + stored);
-        __syncthreads();
-        const uint32_t v0 = c * CH + 2 * piece;
-        if (interior) {
+        wave_sync();
+        const uint32_t v0 = c * DCH + 2 * piece;
+        U4 ri[PASSES];
+#pragma unroll
+        for (uint32_t i = 0; i < PASSES; i++) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
+        if (__all(c * DCH >= phi && c * DCH + DCH <= phi + stored)) {
+            // every row has all 8 slots of this chunk: read everything, then store everything
+            U4 qt[PASSES], qv[PASSES];
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
                 const uint32_t r = lrow + i * ROWS_PER_PASS;
-                const RowInfo ri = rows[r];
-                store16(a.ts + (ri.base + (int64_t)v0), *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece)));
-                store16(a.val + (ri.base + (int64_t)v0), *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece)));
+                qt[i] = *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece));
+                qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < PASSES; i++) {
+                const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
+#if GTSC_ABLATE == 4
+                asm volatile("" ::"v"(qt[i]), "v"(qv[i]), "v"(idx));
+#else
+                store16(a.ts + idx, qt[i]);
+                store16(a.val + idx, qv[i]);
+#endif
             }
         } else {
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
                 const uint32_t r = lrow + i * ROWS_PER_PASS;
-                const RowInfo ri = rows[r];
-                const bool ok0 = v0 >= ri.lo && v0 < ri.hi;
-                const bool ok1 = v0 + 1 >= ri.lo && v0 + 1 < ri.hi;
+                const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
+                const bool ok0 = v0 >= ri[i].z && v0 < ri[i].w;
+                const bool ok1 = v0 + 1 >= ri[i].z && v0 + 1 < ri[i].w;
                 if (ok0 || ok1) {
                     const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece));
                     const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
-                    int64_t* pt = a.ts + (ri.base + (int64_t)v0);
-                    uint64_t* pv = a.val + (ri.base + (int64_t)v0);
                     if (ok0 && ok1) {
-                        store16(pt, t);
-                        store16(pv, v);
+                        store16(a.ts + idx, t);
+                        store16(a.val + idx, v);
                     } else if (ok0) {
-                        pt[0] = (int64_t)lo64(t);
-                        pv[0] = lo64(v);
+                        a.ts[idx] = (int64_t)lo64(t);
+                        a.val[idx] = lo64(v);
                     } else {
-                        pt[1] = (int64_t)hi64(t);
-                        pv[1] = hi64(v);
+                        a.ts[idx + 1] = (int64_t)hi64(t);
+                        a.val[idx + 1] = hi64(v);
                     }
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
+        GTSC_TICK(tk_flush)
     }
+#undef GTSC_TOPUP_LAND
+#undef GTSC_TOPUP_ISSUE
     if (valid) {
         if (n > cap) st |= ST_OVERFLOW;
         st |= d.st;
@@ -478,6 +639,10 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
     }
+#ifdef GTSC_STAMP
+    wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
+    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; }
+#endif
 }
 
 // ------------------------------------------------------------------------

@@ -25,3 +25,14 @@ tot = d.sum(1).mean()
 for i, n in enumerate(names):
     print("%-28s mean %9.0f cycles/wave  (%.1f%%)" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot))
 print("total %.0f cycles/wave = %.1f us at 100 MHz ticks?" % (tot, tot / 100))
+# ---- decode stamps: lane 0 of each wave leaves {compute, flush} cycles in out_npoints[s+1], [s+2]
+ts2 = torch.zeros_like(ts); val2 = torch.zeros_like(val)
+npts = torch.zeros(S, dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()
+for _ in range(2):
+    ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P)
+ctx.sync()
+d = npts.view(-1, 64)[:, 1:3].cpu().numpy().astype(np.float64)
+tot = d.sum(1).mean()
+for i, n in enumerate(["decode compute", "decode flush"]):
+    print("%-28s mean %9.0f cycles/wave  (%.1f%%)" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot))

@@ -135,6 +135,27 @@ __global__ __launch_bounds__(64) void read_rows128_lds(const char* a, const char
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// stores: each wave writes SEG bytes per row per step to its 64 rows of two arrays
+template <int SEG>
+__global__ __launch_bounds__(64) void write_rows(char* a, char* b, size_t rowb)
+{
+    const unsigned lane = threadIdx.x;
+    constexpr int LPR = SEG / 16, RPI = 64 / LPR, NI = 64 / RPI;
+    const size_t tile = (size_t)blockIdx.x * 64 * rowb;
+    const int steps = (int)(rowb / SEG);
+    for (int c = 0; c < steps; c++) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const size_t row = (size_t)i * RPI + lane / LPR;
+            const size_t off = tile + row * rowb + (size_t)c * SEG + (lane % LPR) * 16;
+            const U4 v = {lane, (unsigned)c, (unsigned)i, 7u};
+            *reinterpret_cast<U4*>(a + off) = v;
+            *reinterpret_cast<U4*>(b + off) = v;
+        }
+        __builtin_amdgcn_s_sleep(8);  // spread the steps in time a little, like a kernel that computes in between
+    }
+}
+
 // contiguous: wave streams its 64*rowb bytes in 1 KiB instructions
 template <int DEPTH>
 __global__ __launch_bounds__(64) void read_contig(const char* a, const char* b, size_t rowb, unsigned* sink)
@@ -198,6 +219,10 @@ int main()
     rep("seg64 d1 lds17K", timeit([&] { read_rows<64, 1, 17408><<<blocks, 64>>>(a, b, rowb, sink); }));
     rep("seg128 lds round trip", timeit([&] { read_rows128_lds<1><<<blocks, 64>>>(a, b, rowb, sink); }));
     rep("seg128 lds + prefetch", timeit([&] { read_rows128_lds<2><<<blocks, 64>>>(a, b, rowb, sink); }));
+    rep("WRITE rows seg64", timeit([&] { write_rows<64><<<blocks, 64>>>(a, b, rowb); }));
+    rep("WRITE rows seg128", timeit([&] { write_rows<128><<<blocks, 64>>>(a, b, rowb); }));
+    rep("WRITE rows seg256", timeit([&] { write_rows<256><<<blocks, 64>>>(a, b, rowb); }));
+    rep("WRITE rows seg1024", timeit([&] { write_rows<1024><<<blocks, 64>>>(a, b, rowb); }));
     rep("seg64 occupancy 8K lds", timeit([&] { read_rows_lds<0, 8192><<<blocks, 64>>>(a, b, rowb, sink); }));
     rep("seg64 occupancy 16K lds", timeit([&] { read_rows_lds<0, 16384><<<blocks, 64>>>(a, b, rowb, sink); }));
     rep("seg64 lds round trip", timeit([&] { read_rows_lds<1, 8192><<<blocks, 64>>>(a, b, rowb, sink); }));
