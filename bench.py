@@ -24,7 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import pygtsc as G  # noqa: E402
-from pygtsc import synth  # noqa: E402
+from pygtsc import shard, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
@@ -95,6 +95,20 @@ def cpu_baseline(block, ts, val, P, sample_series, threads):
         "compress_GBps": round(raw / best_e / 1e9, 3),
         "decompress_GBps": round(raw / best_d / 1e9, 3),
     }
+
+
+def pmc_traffic(workload, S, P, kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE with the gfx950
+    correction + WRITE_SIZE) that tools/profile.sh collected for this same workload, or None.
+    Counters cannot be read from inside the timed process, so the figure is carried in a file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if (t.get("workload"), t.get("series"), t.get("points")) != (workload, S, P):
+        return None
+    return t.get(kernel + "_bytes")
 
 
 def main():
@@ -178,10 +192,7 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, device)
 
     enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
@@ -190,6 +201,7 @@ def main():
     algo_bytes = raw_bytes + 8.0 * total_words + 16.0 * S
     dom, dom_ms = ("encode", enc_ms) if enc_ms >= dec_ms else ("decode", dec_ms)
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = pmc_traffic(args.workload, S, P, dom)
 
     result = {
         "metric": "device-resident Gorilla compress/decompress GB/s of raw (ts,double) points",
@@ -218,7 +230,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(dom_ms, 4),
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
         },

@@ -87,6 +87,13 @@ int check_ctx(gtsc_ctx* ctx)
 
 }  // namespace
 
+// true when any of the given (possibly NULL) pointers is not 8-byte aligned
+template <typename... P>
+static bool misaligned8(P... p)
+{
+    return (((uintptr_t)0 | ... | (uintptr_t)p) & 7u) != 0;
+}
+
 extern "C" {
 
 int gtsc_version(void) { return 1000; }
@@ -175,6 +182,8 @@ int gtsc_encode_device(gtsc_ctx* c, int format, uint64_t nseries, const int64_t*
     if (nseries == 0) return GTSC_OK;
     if (!block_ts || !out_words || !out_nwords) return fail(GTSC_ERR_ARG, "block_ts/out_words/out_nwords must not be NULL");
     if ((!ts || !val) && (pt_off || uniform_npoints)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    if (misaligned8(block_ts, ts, val, pt_off, out_words, out_off, out_nwords))
+        return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
     if (!out_off && uniform_slot_words < 3) return fail(GTSC_ERR_ARG, "uniform_slot_words must be at least 3 (an empty block)");
     DeviceGuard g(c->device);
     EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
@@ -192,6 +201,8 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     if (nseries == 0) return GTSC_OK;
     if (!words || !out_npoints) return fail(GTSC_ERR_ARG, "words/out_npoints must not be NULL");
     if ((!ts || !val) && (pt_off || uniform_capacity)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    if (misaligned8(words, in_off, in_nwords, ts, val, pt_off, out_npoints))
+        return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
     DeviceGuard g(c->device);
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
                  out_npoints, status, c->d_flags};

@@ -1,0 +1,75 @@
+"""Sharding over ranks: bounds arithmetic, and a world_size-2 run over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pygtsc import shard, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_bounds_cover_and_balance():
+    b = synth.skewed(total_points=1 << 16, seed=3)
+    for world in (1, 2, 3, 8):
+        bd = shard.shard_bounds(b.pt_off, world)
+        assert bd[0] == 0 and bd[-1] == b.nseries and np.all(np.diff(bd) >= 0)
+        pts = np.array([int(b.pt_off[bd[r + 1]]) - int(b.pt_off[bd[r]]) for r in range(world)])
+        assert pts.sum() == b.npoints
+        longest = int(np.diff(b.pt_off.astype(np.int64)).max())
+        assert pts.max() <= b.npoints // world + longest + 1  # within one series of ideal
+
+
+def test_bounds_uniform_and_degenerate():
+    assert list(shard.shard_bounds(10, 4)) == [0, 2, 5, 7, 10]
+    assert list(shard.shard_bounds(np.array([0], dtype=np.uint64), 2)) == [0, 0, 0]   # no series
+    assert list(shard.shard_bounds(np.array([0, 5], dtype=np.uint64), 4))[-1] == 1      # fewer series than ranks
+    # shards re-based to zero and contiguous
+    b = synth.ragged_mix(seed=2, nseries=17, pmax=50)
+    got_ts = np.concatenate([shard.shard_of(r, 3, b.block_ts, b.ts, b.val, b.pt_off)[1] for r in range(3)])
+    assert np.array_equal(got_ts, b.ts)
+    for r in range(3):
+        off = shard.shard_of(r, 3, b.block_ts, b.ts, b.val, b.pt_off)[3]
+        assert off[0] == 0 and len(off) >= 1
+
+
+def test_concat_images():
+    w, off = shard.concat_images([np.arange(5, dtype=np.uint64), np.arange(3, dtype=np.uint64)],
+                                 [np.array([0, 2, 5], dtype=np.uint64), np.array([0, 3], dtype=np.uint64)])
+    assert list(off) == [0, 2, 5, 8] and len(w) == 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_world(backend, tmp_path, world=2):
+    out = tmp_path / "result.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "shard_worker.py"), "--backend", backend, "--out", str(out)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res["ok"] and res["world"] == world
+    return res
+
+
+def test_world2_gloo_cpu(tmp_path):
+    """Two ranks over gloo: shards coded separately and concatenated equal the whole batch."""
+    _run_world("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_world2_gloo_gpu(tmp_path):
+    """Same, each rank through the HIP library on the one GPU of the box (gloo for the control plane)."""
+    _run_world("gpu", tmp_path)

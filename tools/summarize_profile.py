@@ -35,3 +35,17 @@ for k, cs in counters.items():
     if "WRITE_SIZE" in cs:
         w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
         print("   written bytes (WRITE_SIZE KiB x1024):    %.4g" % (w * 1024))
+
+# HBM traffic per launch for bench.py's roofline.traffic (default workload only)
+import json
+traffic = {"workload": "gauge", "series": 1000000, "points": 120, "source": os.path.basename(root.rstrip("/"))}
+for k, cs in counters.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2
+        w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
+        name = "encode" if "encode" in k else "decode" if "decode" in k else None
+        if name and "<0>" in k:
+            traffic[name + "_bytes"] = round(f + w)
+            traffic[name + "_fetch_bytes"] = round(f)
+            traffic[name + "_write_bytes"] = round(w)
+json.dump(traffic, open(os.path.join(root, "traffic.json"), "w"), indent=1)
