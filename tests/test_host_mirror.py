@@ -1,0 +1,68 @@
+"""The C++ mirror of the reference classes (gorilla-tsc_amd/host/gorilla.hpp), driven the way the
+reference's tests drive the Java classes (T/EncodeGorillaTest.java:26-61: construct, addValue,
+close, getLongArray, then readPair until null), checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from pygtsc import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gorilla-tsc_amd", "host")
+BIN = os.path.join(HOST, "mirror_test")
+
+
+def test_mirror_header_is_self_contained(tmp_path):
+    """gorilla.hpp compiles on its own (syntax only; no GPU, no link)."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "gorilla.hpp"\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", HOST, "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+@pytest.mark.gpu
+def test_mirror_matches_oracle(tmp_path, golden):
+    assert os.path.exists(BIN), "build gorilla-tsc_amd/host/mirror_test first (make -C gorilla-tsc_amd/host)"
+    series = [(O.V2, 1500400800000, np.zeros(0, np.int64), np.zeros(0, np.uint64))]  # (fmt, block, ts, val); first: testEmptyBlock
+    for name, case in golden["inputs"].items():
+        if "ts" in case:
+            ts = np.array(case["ts"], dtype=np.int64)
+            val = np.array(case["val_bits"], dtype=np.uint64)
+        else:
+            ts = np.array([case["block_ts"] + o for o in case["offsets"]], dtype=np.int64)
+            val = np.array(case["doubles"], dtype=np.float64).view(np.uint64)
+        for fmt in (O.V2, O.V1):
+            series.append((fmt, int(case["block_ts"]), ts, val))
+    b = synth.ragged_mix(seed=5, nseries=40, pmax=200)
+    for s in range(b.nseries):
+        t, v = b.series(s)
+        series.append((O.V2 if s % 3 else O.V1, int(b.block_ts[s]), t, v))
+    inp, outp = tmp_path / "in.txt", tmp_path / "out.txt"
+    with open(inp, "w") as f:
+        f.write("%d\n" % len(series))
+        for fmt, block, ts, val in series:
+            f.write("%d %d %d\n" % (fmt, block, len(ts)))
+            for t, v in zip(ts.tolist(), val.tolist()):
+                f.write("%d %x\n" % (t, v))
+    r = subprocess.run([BIN, str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = open(outp).read().split("\n")
+    pos = 0
+    for fmt, block, ts, val in series:
+        nw = int(lines[pos]); pos += 1
+        words = np.array([int(x, 16) for x in lines[pos:pos + nw]], dtype=np.uint64); pos += nw
+        ref = O.encode_block(block, ts, val, fmt)
+        assert np.array_equal(words, ref), "word image differs from the oracle"
+        npairs = int(lines[pos]); pos += 1
+        assert npairs == len(ts)
+        got = [l.split() for l in lines[pos:pos + npairs]]; pos += npairs
+        assert [int(g[0]) for g in got] == ts.tolist()
+        assert [int(g[1], 16) for g in got] == val.tolist()
+    tail = lines[pos].split()
+    # standalone compressor: 2 points -> header+first+1 point+close = 4 words; cut to 2 words it throws
+    assert tail[0] == "standalone" and int(tail[1]) == len(O.encode_block(1500400800000, np.array([1500400801000, 1500400802000]),
+                                                                           np.array([1.5, 2.5]).view(np.uint64), O.V2))
+    assert tail[4] == "threw" and tail[5] == "1"
+    assert tail[7:9] == ["5", "-3"]
