@@ -422,13 +422,11 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     constexpr uint32_t OFF_VAL = TILE_BYTES;
     constexpr uint32_t OFF_RING = 2 * TILE_BYTES;
     constexpr uint32_t OFF_ROWS = OFF_RING + 64 * IN_RING_ROW_BYTES;
-    constexpr uint32_t OFF_FILL = OFF_ROWS + 64 * sizeof(RowInfo);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_FILL + 64 * 8];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ROWS + 64 * sizeof(RowInfo)];
     uint8_t* const tile_ts = lds;
     uint8_t* const tile_val = lds + OFF_VAL;
     uint8_t* const ring = lds + OFF_RING;
     RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + OFF_ROWS);
-    uint2* const fill = reinterpret_cast<uint2*>(lds + OFF_FILL);  // {words loaded so far, image length}
 
     const uint32_t lane = threadIdx.x;
     const uint64_t s0 = (uint64_t)blockIdx.x * 64;
@@ -442,7 +440,6 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (DCH - 1));
     rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi};
     uint32_t filled = nw ? 0u : IN_DONE;  // this row's ring holds image words [.., filled)
-    fill[lane] = make_uint2(filled, nw);
 
     const uint32_t piece = lane % PIECES;
     const uint32_t lrow = lane / PIECES;  // loader / flusher role: rows lrow + 16i
@@ -461,7 +458,7 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
-            const uint32_t rnw = fill[r].y, w = 2 * piece;
+            const uint32_t rnw = (uint32_t)__shfl((int)nw, (int)r, 64), w = 2 * piece;
             const uint32_t back = (w + 1 < rnw) ? 0u : 1u;
             q[i] = U4{0, 0, 0, 0};
             if (w < rnw && rnw >= 2) q[i] = load16(a.words + a.slots.begin(s0 + r) + (w - back));
@@ -470,7 +467,7 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
             asm volatile("" : "+v"(q[i]));
-            const uint32_t rnw = fill[r].y, w = 2 * piece;
+            const uint32_t rnw = (uint32_t)__shfl((int)nw, (int)r, 64), w = 2 * piece;
             const bool upper = !(w + 1 < rnw) && w < rnw;
             const uint64_t x0 = upper ? hi64(q[i]) : lo64(q[i]);
             const uint64_t x1 = upper ? 0ull : hi64(q[i]);
@@ -506,7 +503,11 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
                 if (sl == 0) { dst[IN_RING_WORDS] = x0; dst[IN_RING_WORDS + 1] = x1; }         \
             }                                                                                  \
         }                                                                                      \
-        if (mine) { filled += IN_RING_BLOCK; if (filled >= nw) filled = IN_DONE; }             \
+        if (mine) {                                                                            \
+            filled += IN_RING_BLOCK;                                                           \
+            if (filled >= nw) filled = IN_DONE;                                                \
+            if (active) limit = (filled == IN_DONE) ? 0xFFFFFFFFu : filled - IN_RING_LOW;      \
+        }                                                                                      \
         pending = false;                                                                       \
         wave_sync();                                                                           \
     }
@@ -516,11 +517,10 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
 #define GTSC_TOPUP_ISSUE(NEED)                                                                 \
     {                                                                                          \
         mine = (NEED);                                                                         \
-        fill[lane].x = mine ? filled : 0xFFFFFFFFu; /* all ones: nothing to do for this row */ \
-        wave_sync();                                                                           \
+        const uint32_t pub = mine ? filled : 0xFFFFFFFFu; /* all ones: nothing to do for this row */ \
         _Pragma("unroll") for (uint32_t i = 0; i < IN_PASSES; i++) {                           \
             const uint32_t r = lane / IN_LPR + i * IN_ROWS_PER_PASS;                           \
-            const uint2 f = fill[r];                                                           \
+            const uint2 f = make_uint2((uint32_t)__shfl((int)pub, (int)r, 64), (uint32_t)__shfl((int)nw, (int)r, 64)); \
             const uint32_t w = f.x + 2 * (lane % IN_LPR); /* image word index */               \
             const bool ok = f.x != 0xFFFFFFFFu && w < f.y;                                     \
             const uint32_t back = (w + 1 < f.y) ? 0u : 1u;                                     \
@@ -531,54 +531,90 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
         wave_sync();                                                                           \
     }
 
-    uint32_t n = 0;  // pairs decoded
+    uint32_t n = 0;     // pairs decoded (keeps counting on a finished lane; nfin holds its result)
+    uint32_t nfin = 0;
     uint32_t st = 0;
+    uint32_t skip = phi;               // slots of the first chunk that lie before the row's first point
+    bool slow_lane = valid;            // this lane's next point needs the serial path (first point, zero timestamp, skip)
+    uint32_t limit = (filled == IN_DONE) ? 0xFFFFFFFFu : filled - IN_RING_LOW;  // top up once widx reaches this
 #ifdef GTSC_STAMP
     uint64_t tk_comp = 0, tk_flush = 0, tk_prev = __builtin_amdgcn_s_memtime();
 #define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define GTSC_TICK(acc_)
 #endif
+#if GTSC_ABLATE == 5 || GTSC_ABLATE == 7
+#define GTSC_TILE_WRITE(P_, X_) asm volatile("" ::"v"(X_));
+#else
+#define GTSC_TILE_WRITE(P_, X_) *reinterpret_cast<uint64_t*>(P_) = (X_);
+#endif
+#if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
+    uint64_t w0, w1, w2;
+    { const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); w0 = w[0]; w1 = w[1]; w2 = w[2]; }
+#define GTSC_WINDOW_READ() asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
+#define GTSC_FORCE_FAST true
+#else
+#define GTSC_WINDOW_READ()                                                                     \
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); \
+        const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+#define GTSC_FORCE_FAST false
+#endif
+// One point of every lane.  Finished lanes ride along on the wholesale path (their rows are
+// bounded at flush time), so a ragged wave keeps using it.
+#define GTSC_POINT(KK)                                                                         \
+    {                                                                                          \
+        GTSC_WINDOW_READ()                                                                     \
+        bool done = false;                                                                     \
+        if (!__any(slow_lane)) {                                                               \
+            uint64_t hi, lo;                                                                   \
+            WindowDecoder<FMT>::window(w0, w1, w2, d.off, hi, lo);                             \
+            const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);                     \
+            WindowDecoder<FMT> t = d;                                                          \
+            t.commit(p);                                                                       \
+            if (GTSC_FORCE_FAST || !__any(active && (d.rare(p) || t.stored_ts == 0))) {        \
+                d = t;                                                                         \
+                GTSC_TILE_WRITE(tile_ts + ad + (KK) * 8, d.stored_ts)                          \
+                GTSC_TILE_WRITE(tile_val + ad + (KK) * 8, d.val)                               \
+                n++;                                                                           \
+                done = true;                                                                   \
+            }                                                                                  \
+        }                                                                                      \
+        if (!done) {                                                                           \
+            if (active) {                                                                      \
+                if (skip) {                                                                    \
+                    skip--;                                                                    \
+                } else {                                                                       \
+                    int64_t t; uint64_t v;                                                     \
+                    if (d.next(w0, w1, w2, t, v)) {                                            \
+                        *reinterpret_cast<uint64_t*>(tile_ts + ad + (KK) * 8) = (uint64_t)t;   \
+                        *reinterpret_cast<uint64_t*>(tile_val + ad + (KK) * 8) = v;            \
+                        n++;                                                                   \
+                    } else {                                                                   \
+                        active = false;                                                        \
+                        nfin = n;                                                              \
+                        limit = 0xFFFFFFFFu;                                                   \
+                    }                                                                          \
+                }                                                                              \
+            }                                                                                  \
+            slow_lane = active && (skip != 0 || d.stored_ts == 0);                             \
+        }                                                                                      \
+    }
     for (uint32_t c = 0; __any(active); c++) {
 #pragma unroll 1
-        for (uint32_t k = 0; k < DCH; k++) {
-            const bool go = active && c * DCH + k >= phi;
-            const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1));
-            const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
-            const uint32_t ad = tile_addr(lane, k >> 1) + ((k & 1) << 3);
-            bool done = false;
-            if (__all(go && d.stored_ts != 0)) {
-                // every lane is at an ordinary point: parse without any per-lane control flow and
-                // commit wholesale unless some lane met the end of its stream or an error
-                uint64_t hi, lo;
-                WindowDecoder<FMT>::window(w0, w1, w2, d.off, hi, lo);
-                const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);
-                if (!__any(d.rare(p))) {
-                    d.commit(p);
-                    *reinterpret_cast<uint64_t*>(tile_ts + ad) = d.stored_ts;
-                    *reinterpret_cast<uint64_t*>(tile_val + ad) = d.val;
-                    n++;
-                    done = true;
-                }
-            }
-            if (!done && go) {
-                int64_t t; uint64_t v;
-                if (d.next(w0, w1, w2, t, v)) {
-                    *reinterpret_cast<uint64_t*>(tile_ts + ad) = (uint64_t)t;
-                    *reinterpret_cast<uint64_t*>(tile_val + ad) = v;
-                    n++;
-                } else {
-                    active = false;
-                }
-            }
-            if (k & 1) {
-                if (pending) GTSC_TOPUP_LAND()
-                const bool low = active && filled != IN_DONE && filled - d.widx <= IN_RING_LOW;
-                if (__any(low)) GTSC_TOPUP_ISSUE(low)
-            }
+        for (uint32_t k2 = 0; k2 < DCH / 2; k2++) {
+            const uint32_t ad = tile_addr(lane, k2);
+            GTSC_POINT(0)
+            GTSC_POINT(1)
+            if (pending) GTSC_TOPUP_LAND()
+            const bool low = d.widx >= limit;
+            if (__any(low)) GTSC_TOPUP_ISSUE(low)
         }
+#if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
+        if (active && c * DCH >= cap) { active = false; nfin = n; }
+#endif
         GTSC_TICK(tk_comp)
-        const uint32_t stored = n < cap ? n : cap;  // points of this row that may be written out
+        const uint32_t nn = active ? n : nfin;
+        const uint32_t stored = nn < cap ? nn : cap;  // points of this row that may be written out
         rows[lane].hi = phi + stored;
         wave_sync();
         const uint32_t v0 = c * DCH + 2 * piece;
@@ -632,6 +668,8 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     }
 #undef GTSC_TOPUP_LAND
 #undef GTSC_TOPUP_ISSUE
+#undef GTSC_POINT
+    n = active ? n : nfin;
     if (valid) {
         if (n > cap) st |= ST_OVERFLOW;
         st |= d.st;
