@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--points", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-series", type=int, default=262144)
+    ap.add_argument("--slot-words", type=int, default=0, help="words per output slot (default: the worst case for --points)")
     ap.add_argument("--no-verify", action="store_true", help="skip the round-trip check (kernel experiments only)")
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main():
 
     S, P = args.series, args.points
     block, ts, val = make_workload(args.workload, S, P, device, 0x5EED0002 + rank)
-    slot = G.max_words(P)
+    slot = args.slot_words or G.max_words(P)
     out = torch.zeros(S * slot, dtype=torch.int64, device=device)
     nw = torch.zeros(S, dtype=torch.int64, device=device)
     ts2 = torch.zeros_like(ts)

@@ -146,6 +146,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
     return x;
 }
 
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, uint32_t src_lane)
+{
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, (int)src_lane, 64);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), (int)src_lane, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // what a loader lane needs to know about a row
 struct alignas(16) RowInfo {
     int64_t base;  // array index of virtual slot 0 (first point index - phi)
@@ -196,7 +203,7 @@ template <int FMT> struct TsTile {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(64) void encode_tiled_kernel(EncodeArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void encode_tiled_kernel(EncodeArgs a)
 {
     using TT = TsTile<FMT>;
     constexpr uint32_t OFF_VAL = TT::BYTES;
@@ -417,7 +424,7 @@ constexpr uint32_t IN_ROWS_PER_PASS = 64 / IN_LPR;
 constexpr uint32_t IN_PASSES = 64 / IN_ROWS_PER_PASS;
 
 template <int FMT>
-__global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void decode_tiled_kernel(DecodeArgs a)
 {
     constexpr uint32_t OFF_VAL = TILE_BYTES;
     constexpr uint32_t OFF_RING = 2 * TILE_BYTES;
@@ -428,18 +435,42 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     uint8_t* const ring = lds + OFF_RING;
     RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + OFF_ROWS);
 
+#ifdef GTSC_STAMP
+    const uint64_t tk_entry = __builtin_amdgcn_s_memtime();
+    uint64_t tk_p1 = 0, tk_p2 = 0;
+#endif
     const uint32_t lane = threadIdx.x;
     const uint64_t s0 = (uint64_t)blockIdx.x * 64;
     const uint64_t s = s0 + lane;
     const bool valid = s < a.nseries;
-    uint64_t nw64 = valid ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
-    const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
+#ifdef GTSC_STAMP
+    uint64_t tk_pk;
+    {
+        uint32_t probe = valid ? 1u : 0u;
+        asm volatile("" : "+v"(probe));
+        __builtin_amdgcn_sched_barrier(0); tk_pk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    // The slot bounds are known before the image length is: the first 128 bytes of every slot are
+    // requested right away and the length is looked at when they have arrived (one memory
+    // latency instead of two).  Ring words past the image's end are never parsed.
+    const uint64_t ssz64 = valid ? a.slots.size(s) : 0;
+    const uint32_t ssz = ssz64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ssz64;
+    const uint64_t sbeg = valid ? a.slots.begin(s) : 0;  // handed to the loader lanes by shuffle: no loads between their loads
+    const uint64_t nw64 = valid ? (a.in_nwords ? a.in_nwords[s] : ssz64) : 0;
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t cap64 = valid ? a.pts.size(s) : 0;
     const uint32_t cap = cap64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)cap64;
     const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (DCH - 1));
     rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi};
-    uint32_t filled = nw ? 0u : IN_DONE;  // this row's ring holds image words [.., filled)
+#ifdef GTSC_STAMP
+    uint64_t tk_pn;
+    {
+        uint32_t probe = (uint32_t)nw64;
+        asm volatile("" : "+v"(probe));
+        __builtin_amdgcn_sched_barrier(0); tk_pn = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 
     const uint32_t piece = lane % PIECES;
     const uint32_t lrow = lane / PIECES;  // loader / flusher role: rows lrow + 16i
@@ -449,8 +480,8 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     d.widx = 0; d.off = 0; d.st = 0;
     bool active = valid;
 
-    // ---- initial fill: words 0..15 of every image, 8 lanes x 16 bytes per row; all loads are
-    // issued before any is used (an image's last odd word comes as the upper half of the 16
+    // ---- initial fill: words 0..15 of every slot, 8 lanes x 16 bytes per row; all loads are
+    // issued before any is used (a slot's last odd word comes as the upper half of the 16
     // bytes before it, so there is a single load per pass)
     {
         U4 q[PASSES];
@@ -458,26 +489,35 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
-            const uint32_t rnw = (uint32_t)__shfl((int)nw, (int)r, 64), w = 2 * piece;
-            const uint32_t back = (w + 1 < rnw) ? 0u : 1u;
+            const uint32_t rsz = (uint32_t)__shfl((int)ssz, (int)r, 64), w = 2 * piece;
+            const uint32_t back = (w + 1 < rsz) ? 0u : 1u;
             q[i] = U4{0, 0, 0, 0};
-            if (w < rnw && rnw >= 2) q[i] = load16(a.words + a.slots.begin(s0 + r) + (w - back));
+            const uint64_t rbeg = shfl_u64(sbeg, r);
+            if (w < rsz && rsz >= 2) q[i] = load16(a.words + rbeg + (w - back));
         }
+#ifdef GTSC_STAMP
+        __builtin_amdgcn_sched_barrier(0); tk_p1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
             asm volatile("" : "+v"(q[i]));
-            const uint32_t rnw = (uint32_t)__shfl((int)nw, (int)r, 64), w = 2 * piece;
-            const bool upper = !(w + 1 < rnw) && w < rnw;
+            const uint32_t rsz = (uint32_t)__shfl((int)ssz, (int)r, 64), w = 2 * piece;
+            const bool upper = !(w + 1 < rsz) && w < rsz;
             const uint64_t x0 = upper ? hi64(q[i]) : lo64(q[i]);
             const uint64_t x1 = upper ? 0ull : hi64(q[i]);
             uint64_t* dst = reinterpret_cast<uint64_t*>(ring + r * IN_RING_ROW_BYTES) + w;
             dst[0] = x0; dst[1] = x1;
             if (piece == 0) { dst[IN_RING_WORDS] = x0; dst[IN_RING_WORDS + 1] = x1; }
         }
-        filled = (nw <= IN_RING_WORDS) ? IN_DONE : IN_RING_WORDS;
         wave_sync();
+#ifdef GTSC_STAMP
+        __builtin_amdgcn_sched_barrier(0); tk_p2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+    // an image cannot be longer than its slot
+    const uint32_t nw = nw64 > ssz ? ssz : (uint32_t)nw64;
+    uint32_t filled = (nw <= IN_RING_WORDS) ? IN_DONE : IN_RING_WORDS;  // this row's ring holds image words [.., filled)
     if (valid) d.begin(nw, *reinterpret_cast<const uint64_t*>(my_ring));
 
     // ---- top-up state: loads in flight between two checks
@@ -525,7 +565,8 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
             const bool ok = f.x != 0xFFFFFFFFu && w < f.y;                                     \
             const uint32_t back = (w + 1 < f.y) ? 0u : 1u;                                     \
             tw[i] = ok ? ((w & (IN_RING_WORDS - 1)) | (back << 31)) : 0xFFFFFFFFu;             \
-            if (ok) tq[i] = load16(a.words + a.slots.begin(s0 + r) + (w - back));              \
+            const uint64_t rbeg = shfl_u64(sbeg, r);                                           \
+            if (ok) tq[i] = load16(a.words + rbeg + (w - back));                               \
         }                                                                                      \
         pending = true;                                                                        \
         wave_sync();                                                                           \
@@ -539,6 +580,7 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     uint32_t limit = (filled == IN_DONE) ? 0xFFFFFFFFu : filled - IN_RING_LOW;  // top up once widx reaches this
 #ifdef GTSC_STAMP
     uint64_t tk_comp = 0, tk_flush = 0, tk_prev = __builtin_amdgcn_s_memtime();
+    const uint64_t tk_pro = tk_prev - tk_entry;
 #define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define GTSC_TICK(acc_)
@@ -679,7 +721,7 @@ __global__ __launch_bounds__(64) void decode_tiled_kernel(DecodeArgs a)
     }
 #ifdef GTSC_STAMP
     wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
-    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; }
+    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; a.out_npoints[s + 7] = tk_pn - tk_entry; }
 #endif
 }
 
