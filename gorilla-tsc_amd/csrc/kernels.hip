@@ -406,22 +406,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 }
 
 // Decoder geometry.  Output tiles hold 16 slots per row like the encoder's: stores of whole
-// 128-byte lines run about 1.5x faster than 64-byte half lines.  The compressed words reach
-// the lanes through a per-row LDS ring of 16 words.  It is filled with one 128-byte read per
-// row at the start and then topped up in 32-byte blocks whose loads are issued at one check
-// and written to the ring at the next, so their latency hides behind two points of decoding.
-//   check every 2 points; a row is topped up while it holds <= 12 unread words:
-//   it held >= 13 at the previous check and two points consume <= 4, so >= 9 at issue,
-//   >= 5 when the block lands (a point needs 3), and <= 12 + 4 = 16 = capacity after it.
+// 128-byte lines run about 1.5x faster than 64-byte half lines.
+//
+// The compressed words reach a lane through its own LDS ring of 8 words, which the lane fills
+// itself, 16 bytes at a time: nothing about the input is shared between lanes, so there is no
+// wave-level hand-shake.  (Neighbouring 16-byte pieces of an image come from the same cache
+// line; the compressed stream is the small side of the traffic.)  A top-up is requested when
+// the ring holds <= 6 unread words and is written to the ring at the next check (two points
+// later), so its latency hides behind decoding.  A lane that consumes words faster than that
+// (a point can take 114 bits) is caught by the same comparison that detects the end of the
+// image: the wholesale path only commits a point if the three words of the next window are
+// already in the ring (new position < guard = loaded - 2); otherwise the exact path runs and
+// waits for the missing words.
 constexpr uint32_t DCH = CH;                      // slots per row per chunk
-constexpr uint32_t IN_RING_WORDS = 16;            // ring capacity per row
-constexpr uint32_t IN_RING_BLOCK = 4;             // top-up granule (32 bytes)
-constexpr uint32_t IN_RING_LOW = 12;              // top up while unread words <= this
-constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 2) * 8;  // + mirror of slots 0 and 1: a 3-word window never wraps
-constexpr uint32_t IN_DONE = 0xFFFFFF00u;         // "filled" value of a row whose image is fully loaded
-constexpr uint32_t IN_LPR = IN_RING_BLOCK / 2;    // loader lanes per row (two words each)
-constexpr uint32_t IN_ROWS_PER_PASS = 64 / IN_LPR;
-constexpr uint32_t IN_PASSES = 64 / IN_ROWS_PER_PASS;
+constexpr uint32_t IN_RING_WORDS = 8;             // ring capacity per row
+constexpr uint32_t IN_RING_LOW = 6;               // top up while unread words <= this (2 free slots)
+constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 3) * 8;  // + mirror of slots 0 and 1 (a 3-word window never wraps) + bank padding
+constexpr uint32_t IN_NEVER = 0xFFFFFFFFu;        // "limit" of a lane with nothing left to load
 
 template <int FMT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void decode_tiled_kernel(DecodeArgs a)
@@ -451,125 +452,90 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         __builtin_amdgcn_sched_barrier(0); tk_pk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    // The slot bounds are known before the image length is: the first 128 bytes of every slot are
+    // The slot bounds are known before the image length is: the first 64 bytes of the slot are
     // requested right away and the length is looked at when they have arrived (one memory
     // latency instead of two).  Ring words past the image's end are never parsed.
     const uint64_t ssz64 = valid ? a.slots.size(s) : 0;
     const uint32_t ssz = ssz64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ssz64;
-    const uint64_t sbeg = valid ? a.slots.begin(s) : 0;  // handed to the loader lanes by shuffle: no loads between their loads
-    const uint64_t nw64 = valid ? (a.in_nwords ? a.in_nwords[s] : ssz64) : 0;
+    const uint64_t* const image = a.words + (valid ? a.slots.begin(s) : 0);
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t cap64 = valid ? a.pts.size(s) : 0;
     const uint32_t cap = cap64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)cap64;
     const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (DCH - 1));
     rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi};
-#ifdef GTSC_STAMP
-    uint64_t tk_pn;
-    {
-        uint32_t probe = (uint32_t)nw64;
-        asm volatile("" : "+v"(probe));
-        __builtin_amdgcn_sched_barrier(0); tk_pn = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
 
     const uint32_t piece = lane % PIECES;
-    const uint32_t lrow = lane / PIECES;  // loader / flusher role: rows lrow + 16i
-    const uint8_t* const my_ring = ring + lane * IN_RING_ROW_BYTES;
+    const uint32_t lrow = lane / PIECES;  // flusher role: rows lrow + 8i
+    uint64_t* const my_ring = reinterpret_cast<uint64_t*>(ring + lane * IN_RING_ROW_BYTES);
 
     WindowDecoder<FMT> d;
     d.widx = 0; d.off = 0; d.st = 0;
     bool active = valid;
 
-    // ---- initial fill: words 0..15 of every slot, 8 lanes x 16 bytes per row; all loads are
-    // issued before any is used (a slot's last odd word comes as the upper half of the 16
-    // bytes before it, so there is a single load per pass)
+    // 16 bytes of the slot at word `W` (even): a slot's last odd word comes as the upper half of
+    // the 16 bytes before it, so there is one load instruction whatever the case (two arms would
+    // make the compiler wait for each load where they join).  BACK says which half to use.
+#define GTSC_RING_LOAD(Q, BACK, W)                                                             \
+    {                                                                                          \
+        BACK = ((W) + 1 < ssz) ? 0u : 1u;                                                      \
+        if ((W) < ssz && ssz >= 2) Q = load16(image + ((W) - BACK));                           \
+    }
+#define GTSC_RING_STORE(Q, BACK, W)                                                            \
+    {                                                                                          \
+        asm volatile("" : "+v"(Q));                                                            \
+        const uint64_t x0 = (BACK) ? hi64(Q) : lo64(Q);                                        \
+        const uint64_t x1 = (BACK) ? 0ull : hi64(Q);                                           \
+        const uint32_t sl = (W) & (IN_RING_WORDS - 1);                                         \
+        my_ring[sl] = x0; my_ring[sl + 1] = x1;                                                \
+        if (sl == 0) { my_ring[IN_RING_WORDS] = x0; my_ring[IN_RING_WORDS + 1] = x1; }         \
+    }
+    // ---- initial fill: words 0..7 of the lane's own slot (separate variables, not an array: the
+    // compiler would copy a whole array of quads, and wait for its loads, after every conditional load)
+    uint64_t nw64 = ssz64;
     {
-        U4 q[PASSES];
-        wave_sync();
-#pragma unroll
-        for (uint32_t i = 0; i < PASSES; i++) {
-            const uint32_t r = lrow + i * ROWS_PER_PASS;
-            const uint32_t rsz = (uint32_t)__shfl((int)ssz, (int)r, 64), w = 2 * piece;
-            const uint32_t back = (w + 1 < rsz) ? 0u : 1u;
-            q[i] = U4{0, 0, 0, 0};
-            const uint64_t rbeg = shfl_u64(sbeg, r);
-            if (w < rsz && rsz >= 2) q[i] = load16(a.words + rbeg + (w - back));
-        }
+        U4 q0, q1, q2, q3;  // not loaded: left undefined, never parsed
+        uint32_t b0, b1, b2, b3;
+        GTSC_RING_LOAD(q0, b0, 0u)
+        GTSC_RING_LOAD(q1, b1, 2u)
+        GTSC_RING_LOAD(q2, b2, 4u)
+        GTSC_RING_LOAD(q3, b3, 6u)
+        if (valid && a.in_nwords) nw64 = a.in_nwords[s];  // in flight together with the ring's words
 #ifdef GTSC_STAMP
         __builtin_amdgcn_sched_barrier(0); tk_p1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
 #endif
-#pragma unroll
-        for (uint32_t i = 0; i < PASSES; i++) {
-            const uint32_t r = lrow + i * ROWS_PER_PASS;
-            asm volatile("" : "+v"(q[i]));
-            const uint32_t rsz = (uint32_t)__shfl((int)ssz, (int)r, 64), w = 2 * piece;
-            const bool upper = !(w + 1 < rsz) && w < rsz;
-            const uint64_t x0 = upper ? hi64(q[i]) : lo64(q[i]);
-            const uint64_t x1 = upper ? 0ull : hi64(q[i]);
-            uint64_t* dst = reinterpret_cast<uint64_t*>(ring + r * IN_RING_ROW_BYTES) + w;
-            dst[0] = x0; dst[1] = x1;
-            if (piece == 0) { dst[IN_RING_WORDS] = x0; dst[IN_RING_WORDS + 1] = x1; }
-        }
-        wave_sync();
+        GTSC_RING_STORE(q0, b0, 0u)
+        GTSC_RING_STORE(q1, b1, 2u)
+        GTSC_RING_STORE(q2, b2, 4u)
+        GTSC_RING_STORE(q3, b3, 6u)
 #ifdef GTSC_STAMP
         __builtin_amdgcn_sched_barrier(0); tk_p2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
 #endif
     }
     // an image cannot be longer than its slot
     const uint32_t nw = nw64 > ssz ? ssz : (uint32_t)nw64;
-    uint32_t filled = (nw <= IN_RING_WORDS) ? IN_DONE : IN_RING_WORDS;  // this row's ring holds image words [.., filled)
-    if (valid) d.begin(nw, *reinterpret_cast<const uint64_t*>(my_ring));
+    uint32_t filled = IN_RING_WORDS;  // the ring holds image words [filled - 8, filled) (an even number)
+    // wholesale commits need new widx < guard; top-ups are requested once widx >= limit
+    uint32_t guard = filled >= nw ? nw : filled - 2;
+    uint32_t limit = filled >= nw ? IN_NEVER : filled - IN_RING_LOW;
+    if (valid) d.begin(nw, my_ring[0]);
 
-    // ---- top-up state: loads in flight between two checks
-    bool pending = false;       // wave-uniform: a top-up has been issued and not yet landed
-    bool mine = false;          // this lane's row is part of it
-    U4 tq[IN_PASSES];           // what this lane loaded for rows lane/2 + 32i
-    uint32_t tw[IN_PASSES];     // ring slot it goes to, bit 31 = use the upper half only, all ones = nothing
-#pragma unroll
-    for (uint32_t i = 0; i < IN_PASSES; i++) { tq[i] = U4{0, 0, 0, 0}; tw[i] = 0xFFFFFFFFu; }
-
+    // ---- top-up state: the lane's load in flight between two checks
+    bool pend = false;
+    U4 tq;  // defined whenever pend is set
+    uint32_t tback = 0;
 #define GTSC_TOPUP_LAND()                                                                      \
     {                                                                                          \
-        _Pragma("unroll") for (uint32_t i = 0; i < IN_PASSES; i++) {                           \
-            if (tw[i] != 0xFFFFFFFFu) {                                                        \
-                asm volatile("" : "+v"(tq[i]));                                                \
-                const uint32_t r = lane / IN_LPR + i * IN_ROWS_PER_PASS;                       \
-                const bool upper = tw[i] >> 31;                                                \
-                const uint64_t x0 = upper ? hi64(tq[i]) : lo64(tq[i]);                         \
-                const uint64_t x1 = upper ? 0ull : hi64(tq[i]);                                \
-                const uint32_t sl = tw[i] & (IN_RING_WORDS - 1);                               \
-                uint64_t* dst = reinterpret_cast<uint64_t*>(ring + r * IN_RING_ROW_BYTES) + sl; \
-                dst[0] = x0; dst[1] = x1;                                                      \
-                if (sl == 0) { dst[IN_RING_WORDS] = x0; dst[IN_RING_WORDS + 1] = x1; }         \
-            }                                                                                  \
-        }                                                                                      \
-        if (mine) {                                                                            \
-            filled += IN_RING_BLOCK;                                                           \
-            if (filled >= nw) filled = IN_DONE;                                                \
-            if (active) limit = (filled == IN_DONE) ? 0xFFFFFFFFu : filled - IN_RING_LOW;      \
-        }                                                                                      \
-        pending = false;                                                                       \
-        wave_sync();                                                                           \
+        GTSC_RING_STORE(tq, tback, filled)                                                     \
+        filled += 2;                                                                           \
+        guard = filled >= nw ? nw : filled - 2;                                                \
+        limit = (filled >= nw || !active) ? IN_NEVER : filled - IN_RING_LOW;                   \
+        pend = false;                                                                          \
     }
-// Lane l serves row 32i + l/2, words 2*(l%2) and the next of the row's next block.  One load
-// instruction per pass whatever the case (an image's last odd word is fetched as the upper
-// half of the 16 bytes before it), so that nothing waits for the data here.
-#define GTSC_TOPUP_ISSUE(NEED)                                                                 \
+#define GTSC_TOPUP_ISSUE()                                                                     \
     {                                                                                          \
-        mine = (NEED);                                                                         \
-        const uint32_t pub = mine ? filled : 0xFFFFFFFFu; /* all ones: nothing to do for this row */ \
-        _Pragma("unroll") for (uint32_t i = 0; i < IN_PASSES; i++) {                           \
-            const uint32_t r = lane / IN_LPR + i * IN_ROWS_PER_PASS;                           \
-            const uint2 f = make_uint2((uint32_t)__shfl((int)pub, (int)r, 64), (uint32_t)__shfl((int)nw, (int)r, 64)); \
-            const uint32_t w = f.x + 2 * (lane % IN_LPR); /* image word index */               \
-            const bool ok = f.x != 0xFFFFFFFFu && w < f.y;                                     \
-            const uint32_t back = (w + 1 < f.y) ? 0u : 1u;                                     \
-            tw[i] = ok ? ((w & (IN_RING_WORDS - 1)) | (back << 31)) : 0xFFFFFFFFu;             \
-            const uint64_t rbeg = shfl_u64(sbeg, r);                                           \
-            if (ok) tq[i] = load16(a.words + rbeg + (w - back));                               \
-        }                                                                                      \
-        pending = true;                                                                        \
-        wave_sync();                                                                           \
+        GTSC_RING_LOAD(tq, tback, filled)                                                      \
+        pend = true;                                                                           \
+        limit = IN_NEVER; /* nothing more until this one has landed */                         \
     }
 
     uint32_t n = 0;     // pairs decoded (keeps counting on a finished lane; nfin holds its result)
@@ -577,7 +543,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t st = 0;
     uint32_t skip = phi;               // slots of the first chunk that lie before the row's first point
     bool slow_lane = valid;            // this lane's next point needs the serial path (first point, zero timestamp, skip)
-    uint32_t limit = (filled == IN_DONE) ? 0xFFFFFFFFu : filled - IN_RING_LOW;  // top up once widx reaches this
 #ifdef GTSC_STAMP
     uint64_t tk_comp = 0, tk_flush = 0, tk_prev = __builtin_amdgcn_s_memtime();
     const uint64_t tk_pro = tk_prev - tk_entry;
@@ -613,7 +578,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);                     \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
-            if (GTSC_FORCE_FAST || !__any(active && (d.rare(p) || t.stored_ts == 0))) {        \
+            if (GTSC_FORCE_FAST || !__any(active && (p.eos || p.malformed || t.widx >= guard || t.stored_ts == 0))) { \
                 d = t;                                                                         \
                 GTSC_TILE_WRITE(tile_ts + ad + (KK) * 8, d.stored_ts)                          \
                 GTSC_TILE_WRITE(tile_val + ad + (KK) * 8, d.val)                               \
@@ -634,8 +599,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     } else {                                                                   \
                         active = false;                                                        \
                         nfin = n;                                                              \
-                        limit = 0xFFFFFFFFu;                                                   \
+                        limit = IN_NEVER;                                                      \
                     }                                                                          \
+                }                                                                              \
+            }                                                                                  \
+            /* a lane that has run ahead of its top-ups waits for the words of its next window */ \
+            for (;;) {                                                                         \
+                const bool shortw = active && filled < nw && d.widx + 2 >= filled;             \
+                if (!__any(shortw)) break;                                                     \
+                if (shortw) {                                                                  \
+                    if (!pend) GTSC_TOPUP_ISSUE()                                              \
+                    GTSC_TOPUP_LAND()                                                          \
                 }                                                                              \
             }                                                                                  \
             slow_lane = active && (skip != 0 || d.stored_ts == 0);                             \
@@ -647,9 +621,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const uint32_t ad = tile_addr(lane, k2);
             GTSC_POINT(0)
             GTSC_POINT(1)
-            if (pending) GTSC_TOPUP_LAND()
+            if (__any(pend)) { if (pend) GTSC_TOPUP_LAND() }
             const bool low = d.widx >= limit;
-            if (__any(low)) GTSC_TOPUP_ISSUE(low)
+            if (__any(low)) { if (low) GTSC_TOPUP_ISSUE() }
         }
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
         if (active && c * DCH >= cap) { active = false; nfin = n; }
@@ -710,6 +684,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     }
 #undef GTSC_TOPUP_LAND
 #undef GTSC_TOPUP_ISSUE
+#undef GTSC_RING_LOAD
+#undef GTSC_RING_STORE
 #undef GTSC_POINT
     n = active ? n : nfin;
     if (valid) {
@@ -721,7 +697,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     }
 #ifdef GTSC_STAMP
     wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
-    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; a.out_npoints[s + 7] = tk_pn - tk_entry; }
+    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; }
 #endif
 }
 
