@@ -424,17 +424,34 @@ constexpr uint32_t IN_RING_LOW = 6;               // top up while unread words <
 constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 3) * 8;  // + mirror of slots 0 and 1 (a 3-word window never wraps) + bank padding
 constexpr uint32_t IN_NEVER = 0xFFFFFFFFu;        // "limit" of a lane with nothing left to load
 
+// The decoder's timestamp tile holds only the low half of each timestamp (4 bytes per slot):
+// within a chunk of 16 points the high half practically never changes, so a row carries one
+// high half per chunk (DecRow::ts_hi) and the flush puts the two together.  A point whose high
+// half differs from its row's (a 2^32 ms boundary, or wild input) is written to memory by its
+// own lane right away and masked out of the flush (DecRow::info, bits 16..31).
+constexpr uint32_t DEC_TS_TILE_BYTES = 64 * DCH * 4;
+__device__ __forceinline__ uint32_t dec_ts_addr(uint32_t row, uint32_t slot)
+{
+    return row * (DCH * 4) + ((slot ^ (((row >> 2) & 7) << 1)) << 2);  // even swizzle: a pair of slots stays 8 contiguous bytes
+}
+struct alignas(16) DecRow {
+    int64_t base;    // array index of slot 0 of chunk 0 (first point index - phi)
+    uint32_t info;   // this chunk: first occupied slot | (one past the last) << 8 | (slots written directly) << 16
+    uint32_t ts_hi;  // high half of the chunk's timestamps
+};
+constexpr uint32_t DEC_ROW_FULL = 16u << 8;       // info of a row with all 16 slots to flush
+
 template <int FMT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void decode_tiled_kernel(DecodeArgs a)
 {
-    constexpr uint32_t OFF_VAL = TILE_BYTES;
-    constexpr uint32_t OFF_RING = 2 * TILE_BYTES;
+    constexpr uint32_t OFF_TS = TILE_BYTES;
+    constexpr uint32_t OFF_RING = OFF_TS + DEC_TS_TILE_BYTES;
     constexpr uint32_t OFF_ROWS = OFF_RING + 64 * IN_RING_ROW_BYTES;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ROWS + 64 * sizeof(RowInfo)];
-    uint8_t* const tile_ts = lds;
-    uint8_t* const tile_val = lds + OFF_VAL;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ROWS + 64 * sizeof(DecRow)];
+    uint8_t* const tile_val = lds;
+    uint8_t* const tile_ts = lds + OFF_TS;
     uint8_t* const ring = lds + OFF_RING;
-    RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + OFF_ROWS);
+    DecRow* const rows = reinterpret_cast<DecRow*>(lds + OFF_ROWS);
 
 #ifdef GTSC_STAMP
     const uint64_t tk_entry = __builtin_amdgcn_s_memtime();
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     const uint64_t cap64 = valid ? a.pts.size(s) : 0;
     const uint32_t cap = cap64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)cap64;
     const uint32_t phi = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & (DCH - 1));
-    rows[lane] = RowInfo{(int64_t)p0 - (int64_t)phi, phi, phi};
+    rows[lane] = DecRow{(int64_t)p0 - (int64_t)phi, 0u, 0u};
 
     const uint32_t piece = lane % PIECES;
     const uint32_t lrow = lane / PIECES;  // flusher role: rows lrow + 8i
@@ -543,6 +560,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t st = 0;
     uint32_t skip = phi;               // slots of the first chunk that lie before the row's first point
     bool slow_lane = valid;            // this lane's next point needs the serial path (first point, zero timestamp, skip)
+    uint32_t ts_ref = 0;               // high half that this chunk's timestamps of the lane share
+    uint32_t n0 = 0;                   // n when the chunk began
+    uint32_t dmask = 0;                // slots of this chunk whose timestamps the lane stored itself
 #ifdef GTSC_STAMP
     uint64_t tk_comp = 0, tk_flush = 0, tk_prev = __builtin_amdgcn_s_memtime();
     const uint64_t tk_pro = tk_prev - tk_entry;
@@ -551,9 +571,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #define GTSC_TICK(acc_)
 #endif
 #if GTSC_ABLATE == 5 || GTSC_ABLATE == 7
-#define GTSC_TILE_WRITE(P_, X_) asm volatile("" ::"v"(X_));
+#define GTSC_TILE_WRITE(T_, P_, X_) asm volatile("" ::"v"(X_));
 #else
-#define GTSC_TILE_WRITE(P_, X_) *reinterpret_cast<uint64_t*>(P_) = (X_);
+#define GTSC_TILE_WRITE(T_, P_, X_) *reinterpret_cast<T_*>(P_) = (T_)(X_);
 #endif
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
     uint64_t w0, w1, w2;
@@ -578,10 +598,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);                     \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
-            if (GTSC_FORCE_FAST || !__any(active && (p.eos || p.malformed || t.widx >= guard || t.stored_ts == 0))) { \
+            if (GTSC_FORCE_FAST || !__any(active && (p.eos || p.malformed || t.widx >= guard || t.stored_ts == 0 || \
+                                                     (uint32_t)(t.stored_ts >> 32) != ts_ref))) { \
                 d = t;                                                                         \
-                GTSC_TILE_WRITE(tile_ts + ad + (KK) * 8, d.stored_ts)                          \
-                GTSC_TILE_WRITE(tile_val + ad + (KK) * 8, d.val)                               \
+                GTSC_TILE_WRITE(uint32_t, tile_ts + adt + (KK) * 4, d.stored_ts)               \
+                GTSC_TILE_WRITE(uint64_t, tile_val + ad + (KK) * 8, d.val)                     \
                 n++;                                                                           \
                 done = true;                                                                   \
             }                                                                                  \
@@ -593,7 +614,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 } else {                                                                       \
                     int64_t t; uint64_t v;                                                     \
                     if (d.next(w0, w1, w2, t, v)) {                                            \
-                        *reinterpret_cast<uint64_t*>(tile_ts + ad + (KK) * 8) = (uint64_t)t;   \
+                        const uint32_t h = (uint32_t)((uint64_t)t >> 32);                      \
+                        if (h != ts_ref) {                                                     \
+                            if (n == n0) {                                                     \
+                                ts_ref = h; /* first point of the chunk sets the row's high half */ \
+                            } else {                                                           \
+                                dmask |= 1u << (2 * k2 + (KK));                                \
+                                if (n < cap) a.ts[p0 + n] = t;                                 \
+                            }                                                                  \
+                        }                                                                      \
+                        *reinterpret_cast<uint32_t*>(tile_ts + adt + (KK) * 4) = (uint32_t)t;  \
                         *reinterpret_cast<uint64_t*>(tile_val + ad + (KK) * 8) = v;            \
                         n++;                                                                   \
                     } else {                                                                   \
@@ -616,9 +646,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         }                                                                                      \
     }
     for (uint32_t c = 0; __any(active); c++) {
+        ts_ref = (uint32_t)(d.stored_ts >> 32);
+        n0 = n;
+        dmask = 0;
 #pragma unroll 1
         for (uint32_t k2 = 0; k2 < DCH / 2; k2++) {
             const uint32_t ad = tile_addr(lane, k2);
+            const uint32_t adt = dec_ts_addr(lane, 2 * k2);
             GTSC_POINT(0)
             GTSC_POINT(1)
             if (__any(pend)) { if (pend) GTSC_TOPUP_LAND() }
@@ -629,30 +663,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (active && c * DCH >= cap) { active = false; nfin = n; }
 #endif
         GTSC_TICK(tk_comp)
+        // ---- flush the chunk: what this row has to write out, in slots of this chunk
         const uint32_t nn = active ? n : nfin;
         const uint32_t stored = nn < cap ? nn : cap;  // points of this row that may be written out
-        rows[lane].hi = phi + stored;
+        const uint32_t end = phi + stored;            // in slots counted from chunk 0
+        const uint32_t lo_rel = c == 0 ? phi : 0u;
+        const uint32_t hi_rel = end <= c * DCH ? 0u : (end - c * DCH < DCH ? end - c * DCH : DCH);
+        const uint32_t info = lo_rel | (hi_rel << 8) | (dmask << 16);
+        *reinterpret_cast<uint2*>(&rows[lane].info) = make_uint2(info, ts_ref);
         wave_sync();
-        const uint32_t v0 = c * DCH + 2 * piece;
+        const uint32_t j0 = 2 * piece;
+        const uint32_t v0 = c * DCH + j0;
         U4 ri[PASSES];
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
-        if (__all(c * DCH >= phi && c * DCH + DCH <= phi + stored)) {
-            // every row has all 8 slots of this chunk: read everything, then store everything
-            U4 qt[PASSES], qv[PASSES];
+        if (__all(info == DEC_ROW_FULL)) {
+            // every row has all 16 slots of this chunk: read everything, then store everything
+            uint2 qt[PASSES];
+            U4 qv[PASSES];
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
                 const uint32_t r = lrow + i * ROWS_PER_PASS;
-                qt[i] = *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece));
+                qt[i] = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
                 qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
             }
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
                 const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
+                const U4 t = {qt[i].x, ri[i].w, qt[i].y, ri[i].w};
 #if GTSC_ABLATE == 4
-                asm volatile("" ::"v"(qt[i]), "v"(qv[i]), "v"(idx));
+                asm volatile("" ::"v"(t), "v"(qv[i]), "v"(idx));
 #else
-                store16(a.ts + idx, qt[i]);
+                store16(a.ts + idx, t);
                 store16(a.val + idx, qv[i]);
 #endif
             }
@@ -661,19 +703,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             for (uint32_t i = 0; i < PASSES; i++) {
                 const uint32_t r = lrow + i * ROWS_PER_PASS;
                 const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
-                const bool ok0 = v0 >= ri[i].z && v0 < ri[i].w;
-                const bool ok1 = v0 + 1 >= ri[i].z && v0 + 1 < ri[i].w;
+                const uint32_t rlo = ri[i].z & 255u, rhi = (ri[i].z >> 8) & 255u, direct = ri[i].z >> 16;
+                const bool ok0 = j0 >= rlo && j0 < rhi;
+                const bool ok1 = j0 + 1 >= rlo && j0 + 1 < rhi;
                 if (ok0 || ok1) {
-                    const U4 t = *reinterpret_cast<const U4*>(tile_ts + tile_addr(r, piece));
+                    const uint2 tl = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
                     const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
+                    const bool t0 = ok0 && !((direct >> j0) & 1u), t1 = ok1 && !((direct >> (j0 + 1)) & 1u);
+                    const uint64_t ts0 = ((uint64_t)ri[i].w << 32) | tl.x, ts1 = ((uint64_t)ri[i].w << 32) | tl.y;
+                    if (t0 && t1) {
+                        store16(a.ts + idx, U4{tl.x, ri[i].w, tl.y, ri[i].w});
+                    } else {
+                        if (t0) a.ts[idx] = (int64_t)ts0;
+                        if (t1) a.ts[idx + 1] = (int64_t)ts1;
+                    }
                     if (ok0 && ok1) {
-                        store16(a.ts + idx, t);
                         store16(a.val + idx, v);
                     } else if (ok0) {
-                        a.ts[idx] = (int64_t)lo64(t);
                         a.val[idx] = lo64(v);
                     } else {
-                        a.ts[idx + 1] = (int64_t)hi64(t);
                         a.val[idx + 1] = hi64(v);
                     }
                 }

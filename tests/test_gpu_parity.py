@@ -289,6 +289,54 @@ def test_quirks_first_ts_zero_and_int_wrap(ctx, gfmt, ofmt):
         assert np.array_equal(ts[a:a + n], rts[a:a + n]) and np.array_equal(val[a:a + n], rval[a:a + n])
 
 
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_timestamp_high_half_changes_inside_a_chunk(ctx, gfmt, ofmt):
+    """Timestamps that cross multiples of 2^32 at every position of a 16-point chunk, jump back
+    and forth over one, and series whose high half changes at nearly every point: the decoder
+    keeps one high half per row and chunk and must still return every timestamp exactly."""
+    rng = np.random.default_rng(99)
+    series = []
+    for k in range(70):  # crossing after k points, steps of 1 s
+        edge = (350 + k) << 32
+        P = 40 + (k % 37)
+        first = edge - 1000 * (k % 33) - 500
+        series.append((first - 1000, first + 1000 * np.arange(P, dtype=np.int64)))
+    for k in range(40):  # see-saw over an edge with steps near +-2^31
+        edge = (400 + k) << 32
+        P = 30 + k
+        step = np.where(np.arange(P) % 2 == 0, 2 ** 31 - 1 - k, -(2 ** 31) + 1 + 3 * k).astype(np.int64)
+        t = edge - 2 ** 30 + np.cumsum(step)
+        series.append((int(t[0]) - 5, t))
+    for k in range(30):  # random walk with steps up to +-2^31-1
+        P = 20 + 5 * k
+        t = ((500 + k) << 32) + np.cumsum(rng.integers(-(2 ** 31) + 1, 2 ** 31 - 1, P))
+        series.append((int(t[0]) - 100, t.astype(np.int64)))
+    pt_off = np.zeros(len(series) + 1, dtype=np.uint64)
+    np.cumsum([len(s[1]) for s in series], out=pt_off[1:])
+    ts = np.concatenate([s[1] for s in series]).astype(np.int64)
+    val = rng.integers(0, 2 ** 63, len(ts), dtype=np.int64).view(np.uint64)
+    val[::3] = val[1::3][: len(val[::3])] if len(val[1::3]) >= len(val[::3]) else val[::3]
+    b = synth.Batch(np.array([s[0] for s in series], dtype=np.int64), ts, val, pt_off)
+    out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt)
+    gts, gval, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, gfmt)
+    rts, rval, rnp, rst = O.decode_batch(out, off, nw, b.pt_off, fmt=ofmt)
+    assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+    assert np.array_equal(gts, rts) and np.array_equal(gval, rval)
+    # the regular-cadence group round-trips (the others overflow the format's int delta-of-delta)
+    n_reg = int(b.pt_off[70])
+    assert np.array_equal(gts[:n_reg], b.ts[:n_reg]) and np.array_equal(gval[:n_reg], b.val[:n_reg])
+    # a smaller capacity than the series has: nothing may be written past a row's slot
+    cap_off = (b.pt_off // np.uint64(2)).astype(np.uint64)
+    gts2, gval2, npts2, st2, rc2 = gpu_decode(ctx, out, off, nw, cap_off, gfmt)
+    rts2, rval2, rnp2, rst2 = O.decode_batch(out, off, nw, cap_off, fmt=ofmt)
+    assert np.array_equal(npts2, rnp2) and np.array_equal(st2, rst2)
+    for s in range(len(series)):
+        a0, a1 = int(cap_off[s]), int(cap_off[s + 1])
+        n = min(int(npts2[s]), a1 - a0)
+        assert np.array_equal(gts2[a0:a0 + n], rts2[a0:a0 + n]) and np.array_equal(gval2[a0:a0 + n], rval2[a0:a0 + n])
+        assert np.all(gts2[a0 + n:a1] == -7)  # untouched fill pattern
+
+
 def test_host_entry_points(ctx):
     b = synth.ragged_mix(seed=5, nseries=2500, pmax=300)
     for gfmt, ofmt in FMTS:
