@@ -339,7 +339,10 @@ struct WindowDecoder {
     uint32_t st;
     int64_t block_ts, stored_delta;
     uint64_t stored_ts, val;
-    uint32_t lead;
+    // The value window as (significant bits, trailing zeros): the reference keeps (leading,
+    // trailing) and reads 64 - leading - trailing bits (G/ValueDecompressor.java:44-52), which is
+    // the significant-bit count of the header that set the window.  0 = no window yet.
+    uint32_t nbits;
     int32_t trail;
 
     // true when a field ending o bits into the window runs off the image (the reader's
@@ -353,7 +356,7 @@ struct WindowDecoder {
         nwords = nwords_;
         widx = 0; off = 0;
         stored_ts = 0; stored_delta = 0; val = 0;
-        lead = NO_WINDOW; trail = 0;
+        nbits = 0; trail = 0;
         block_ts = (int64_t)w0;
         st = runs_off(64) ? ST_TRUNCATED : 0u;  // also covers nwords == 0
         advance(64);
@@ -362,7 +365,7 @@ struct WindowDecoder {
     // What one ordinary (not first) point parses to, before anything is committed.
     struct Parsed {
         uint32_t o1, o2, o3;  // window offsets after the timestamp code, the value header, the payload
-        uint32_t lead;
+        uint32_t nbits;
         int32_t trail;
         uint64_t bits;        // payload, right-aligned
         int64_t dd;           // delta of delta
@@ -373,13 +376,16 @@ struct WindowDecoder {
     __device__ __forceinline__ Parsed parse(uint64_t hi, uint64_t lo) const
     {
         Parsed p;
-        // ---- timestamp: leading ones of the next four bits select the bucket
+        // ---- timestamp: leading ones of the next four bits select the bucket; payload width
+        // 0, 7, 9, 12, 32 and code length 1, 9, 12, 16, 36 sit in 6-bit fields of two constants
         const uint32_t top = (uint32_t)(hi >> 32);
         uint32_t ones = (uint32_t)__clz((int)~top);  // 32 when all ones
         ones = ones > 4 ? 4u : ones;
-        // payload width 0, 7, 9, 12, 32 and code length 1, 9, 12, 16, 36
-        const uint32_t plen = ones == 4 ? 32u : ((0x0C090700u >> (8 * ones)) & 0xFFu);
-        const uint32_t clen = plen + (ones < 4 ? ones + 1u : 4u);
+        constexpr uint32_t PLEN = 0u | (7u << 6) | (9u << 12) | (12u << 18) | (32u << 24);
+        constexpr uint32_t CLEN = 1u | (9u << 6) | (12u << 12) | (16u << 18) | (36u << 24);
+        const uint32_t f = ones * 6u;
+        const uint32_t plen = (PLEN >> f) & 63u;
+        const uint32_t clen = (CLEN >> f) & 63u;
         const uint32_t raw = (uint32_t)(hi >> (64 - clen)) & (uint32_t)~(~0ull << plen);
         p.eos = ones == 4 && raw == 0xFFFFFFFFu;
         int64_t dd;
@@ -393,40 +399,38 @@ struct WindowDecoder {
             dd = (int64_t)(int32_t)ext;
         }
         p.dd = ones ? dd : 0;
-        // ---- value header: the 14 bits after the timestamp code (clen + 14 <= 50)
-        const uint32_t h = (uint32_t)((hi << clen) >> 50);
-        const bool c0 = (h >> 13) & 1u, c1 = (h >> 12) & 1u;
-        const bool fresh = c0 && c1;
-        uint32_t nlead, hlen;
-        int32_t ntrail;
+        // ---- value header: the bits after the timestamp code, left-aligned in xh (clen + 14 <= 50)
+        const uint32_t xh = (uint32_t)((hi << clen) >> 32);
+        const bool c0 = (int32_t)xh < 0;          // '1': the value changed
+        const bool fresh = xh >= 0xC0000000u;     // '11': a new window follows
+        uint32_t nlead, sig, hlen;
         if (FMT == FMT_V2) {
-            nlead = (h >> 6) & 63u;
-            ntrail = 63 - (int32_t)(h & 63u) - (int32_t)nlead;
+            nlead = (xh >> 24) & 63u;             // 6 bits of leading zeros, 6 bits of (significant - 1)
+            sig = ((xh >> 18) & 63u) + 1u;
             hlen = 14;
         } else {
-            nlead = (h >> 7) & 31u;
-            uint32_t sig = (h >> 1) & 63u;
+            nlead = (xh >> 25) & 31u;             // 5 bits of leading zeros, 6 bits of significant, 0 = 64
+            sig = (xh >> 19) & 63u;
             sig = sig ? sig : 64u;
-            ntrail = 64 - (int32_t)sig - (int32_t)nlead;
             hlen = 13;
         }
-        p.lead = fresh ? nlead : lead;
-        p.trail = fresh ? ntrail : trail;
-        hlen = c0 ? (c1 ? hlen : 2u) : 1u;
+        p.nbits = fresh ? sig : nbits;
+        p.trail = fresh ? 64 - (int32_t)sig - (int32_t)nlead : trail;
+        hlen = c0 ? (fresh ? hlen : 2u) : 1u;
         const uint32_t p2 = clen + hlen;  // <= 50: start of the payload inside (hi,lo)
-        p.malformed = c0 && p.lead == NO_WINDOW;
-        const uint32_t n = c0 ? (uint32_t)(64 - (int32_t)p.lead - p.trail) & 127u : 0u;  // 1..64 once a window exists
+        p.malformed = c0 && p.nbits == 0;
+        const uint32_t n = c0 ? p.nbits : 0u;  // 1..64 once a window exists
         const uint64_t pay = (hi << p2) | ((lo >> 1) >> (63 - p2));
         p.bits = n ? (pay >> ((64u - n) & 63u)) : 0ull;
         p.o1 = off + clen;
         p.o2 = off + p2;
-        p.o3 = p.o2 + (p.malformed ? 0u : n);
+        p.o3 = p.o2 + n;
         return p;
     }
     __device__ __forceinline__ bool rare(const Parsed& p) const { return p.eos || p.malformed || runs_off(p.o3); }
     __device__ __forceinline__ void commit(const Parsed& p)
     {
-        lead = p.lead;
+        nbits = p.nbits;
         trail = p.trail;
         val ^= p.bits << ((uint32_t)p.trail & 63u);  // Java shifts by the count mod 64
         stored_delta = (int64_t)((uint64_t)stored_delta + (uint64_t)p.dd);
