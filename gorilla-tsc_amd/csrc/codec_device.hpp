@@ -387,7 +387,7 @@ struct WindowDecoder {
         const uint32_t plen = (PLEN >> f) & 63u;
         const uint32_t clen = (CLEN >> f) & 63u;
         const uint32_t raw = (uint32_t)(hi >> (64 - clen)) & (uint32_t)~(~0ull << plen);
-        p.eos = ones == 4 && raw == 0xFFFFFFFFu;
+        p.eos = raw == 0xFFFFFFFFu;  // only the 32-bit payload can hold it
         int64_t dd;
         if (FMT == FMT_V2) {
             const uint32_t z = raw + 1u;
@@ -418,7 +418,7 @@ struct WindowDecoder {
         p.trail = fresh ? 64 - (int32_t)sig - (int32_t)nlead : trail;
         hlen = c0 ? (fresh ? hlen : 2u) : 1u;
         const uint32_t p2 = clen + hlen;  // <= 50: start of the payload inside (hi,lo)
-        p.malformed = c0 && p.nbits == 0;
+        p.malformed = c0 & (p.nbits == 0);
         const uint32_t n = c0 ? p.nbits : 0u;  // 1..64 once a window exists
         const uint64_t pay = (hi << p2) | ((lo >> 1) >> (63 - p2));
         p.bits = n ? (pay >> ((64u - n) & 63u)) : 0ull;

@@ -598,8 +598,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);                     \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
-            if (GTSC_FORCE_FAST || !__any(active && (p.eos || p.malformed || t.widx >= guard || t.stored_ts == 0 || \
-                                                     (uint32_t)(t.stored_ts >> 32) != ts_ref))) { \
+            /* plain | and &: short-circuit forms would become a chain of branches */          \
+            const bool rare = active & (p.eos | p.malformed | (t.widx >= guard) | (t.stored_ts == 0) | \
+                                        ((uint32_t)(t.stored_ts >> 32) != ts_ref));            \
+            if (GTSC_FORCE_FAST || !__any(rare)) {                                             \
                 d = t;                                                                         \
                 GTSC_TILE_WRITE(uint32_t, tile_ts + adt + (KK) * 4, d.stored_ts)               \
                 GTSC_TILE_WRITE(uint64_t, tile_val + ad + (KK) * 8, d.val)                     \
