@@ -129,13 +129,19 @@ struct Encoder {
             const uint32_t nd = ts_lo - pts_lo;
             const int32_t dod = (int32_t)(nd - (uint32_t)(int32_t)stored_delta);
             const uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
-            const uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0
+            uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0 (dod == -1)
+            need = need > 13u ? 13u : need;
+            // bucket by bits required, two bits per entry: 0 -> 36-bit code (need 0 or > 12),
+            // 1 -> '10'+7, 2 -> '110'+9, 3 -> '1110'+12   (G/GorillaCompressor.java:110-137)
+            constexpr uint32_t BUCKET = (1u * 0x5554u) | (2u << 16) | (2u << 18) | (3u << 20) | (3u << 22) | (3u << 24);
+            const uint32_t bk = (BUCKET >> (2u * need)) & 3u;
+            constexpr uint32_t LEN = 36u | (9u << 8) | (12u << 16) | (16u << 24);
+            constexpr uint64_t PRE = 0ull | (0x100ull << 16) | (0xC00ull << 32) | (0xE000ull << 48);
             const bool zero = dod == 0;
-            const bool b7 = (need - 1u) < 7u, b9 = (need - 8u) < 2u, b12 = (need - 10u) < 3u;
-            tlen = zero ? 1u : b7 ? 9u : b9 ? 12u : b12 ? 16u : 36u;  // need 0 (dod -1) or > 12: 36
-            const uint32_t pre = b7 ? 0x100u : b9 ? 0xC00u : b12 ? 0xE000u : 0u;
+            tlen = zero ? 1u : (LEN >> (8u * bk)) & 0xFFu;
+            const uint32_t pre = (uint32_t)(PRE >> (16u * bk)) & 0xFFFFu;
             tlo = zero ? 0u : (z | pre);
-            thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
+            thi = (zero || bk != 0) ? 0u : 0xFu;
             stored_delta = (int64_t)(int32_t)nd;
         } else {
             const uint64_t ts = ((uint64_t)ts_hi << 32) | ts_lo, pts = ((uint64_t)pts_hi << 32) | pts_lo;
