@@ -173,22 +173,60 @@ int gtsc_sync(gtsc_ctx* c)
     return GTSC_OK;
 }
 
-int gtsc_encode_device(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* block_ts, const int64_t* ts,
-                       const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints, uint64_t* out_words,
-                       const uint64_t* out_off, uint64_t uniform_slot_words, uint64_t* out_nwords, uint32_t* status)
+int gtsc_encode_device_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nseries, const int64_t* block_ts,
+                          const int64_t* ts, const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints,
+                          uint64_t* out_words, const uint64_t* out_off, uint64_t uniform_slot_words, uint64_t* out_nwords,
+                          uint64_t* out_nbits, uint32_t* status)
 {
     if (int rc = check_ctx(c)) return rc;
     if (format != GTSC_FMT_V2 && format != GTSC_FMT_V1) return fail(GTSC_ERR_ARG, "unknown format %d", format);
+    if (options & ~(uint32_t)GTSC_ENC_NO_CLOSE) return fail(GTSC_ERR_ARG, "unknown encode options 0x%x", options);
     if (nseries == 0) return GTSC_OK;
     if (!block_ts || !out_words || !out_nwords) return fail(GTSC_ERR_ARG, "block_ts/out_words/out_nwords must not be NULL");
     if ((!ts || !val) && (pt_off || uniform_npoints)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
-    if (misaligned8(block_ts, ts, val, pt_off, out_words, out_off, out_nwords))
+    if (misaligned8(block_ts, ts, val, pt_off, out_words, out_off, out_nwords, out_nbits))
         return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
     if (!out_off && uniform_slot_words < 3) return fail(GTSC_ERR_ARG, "uniform_slot_words must be at least 3 (an empty block)");
     DeviceGuard g(c->device);
     EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
-                 out_nwords, status, c->d_flags};
+                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u};
     HIP_TRY(launch_encode(a, format, c->stream));
+    return GTSC_OK;
+}
+
+int gtsc_encode_device(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* block_ts, const int64_t* ts,
+                       const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints, uint64_t* out_words,
+                       const uint64_t* out_off, uint64_t uniform_slot_words, uint64_t* out_nwords, uint32_t* status)
+{
+    return gtsc_encode_device_ex(c, format, 0, nseries, block_ts, ts, val, pt_off, uniform_npoints, out_words, out_off,
+                                 uniform_slot_words, out_nwords, nullptr, status);
+}
+
+int gtsc_words_to_bytes_device(gtsc_ctx* c, uint64_t nseries, const uint64_t* words, const uint64_t* word_off,
+                               uint64_t uniform_slot_words, const uint64_t* nbits, uint8_t* out_bytes,
+                               const uint64_t* byte_off, uint64_t uniform_slot_bytes, uint64_t* out_nbytes)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (nseries == 0) return GTSC_OK;
+    if (!words || !nbits || !out_bytes || !out_nbytes) return fail(GTSC_ERR_ARG, "words/nbits/out_bytes/out_nbytes must not be NULL");
+    if (misaligned8(words, word_off, nbits, byte_off, out_nbytes)) return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_words_to_bytes(nseries, words, Layout{word_off, uniform_slot_words}, nbits, out_bytes,
+                                  Layout{byte_off, uniform_slot_bytes}, out_nbytes, c->d_flags, c->stream));
+    return GTSC_OK;
+}
+
+int gtsc_bytes_to_words_device(gtsc_ctx* c, uint64_t nseries, const uint8_t* bytes, const uint64_t* byte_off,
+                               uint64_t uniform_slot_bytes, const uint64_t* nbytes, uint64_t* out_words,
+                               const uint64_t* word_off, uint64_t uniform_slot_words, uint64_t* out_nwords)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (nseries == 0) return GTSC_OK;
+    if (!bytes || !out_words || !out_nwords) return fail(GTSC_ERR_ARG, "bytes/out_words/out_nwords must not be NULL");
+    if (misaligned8(byte_off, nbytes, out_words, word_off, out_nwords)) return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_bytes_to_words(nseries, bytes, Layout{byte_off, uniform_slot_bytes}, nbytes, out_words,
+                                  Layout{word_off, uniform_slot_words}, out_nwords, c->d_flags, c->stream));
     return GTSC_OK;
 }
 
@@ -372,7 +410,7 @@ int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* b
         }
         EncodeArgs a{ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
                      Layout{d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot},
-                     st.nwords.as<uint64_t>(), nullptr, c->d_flags};
+                     st.nwords.as<uint64_t>(), nullptr, c->d_flags, nullptr, 0u};
         HIP_TRY(launch_encode(a, format, st.stream));
         uint64_t* scratch = c->scan_scratch.as<uint64_t>() + (size_t)b * scan_scratch_words(CHUNK_SERIES);
         HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), ns, st.coff.as<uint64_t>(), scratch, st.stream));

@@ -189,6 +189,18 @@ struct Encoder {
         sink(widx, 0ull); widx++;
         return widx;
     }
+
+    // Bits written so far (N of the stream).
+    __device__ __forceinline__ uint64_t bits() const { return (uint64_t)widx * 64u + nacc; }
+
+    // getLongArray() without close(): the completed words plus the current partial word
+    // (G/LongArrayOutput.java:141-145; T/EncodeGorillaTest.java:483-500).
+    template <class Sink>
+    __device__ __forceinline__ uint32_t snapshot(Sink& sink)
+    {
+        sink(widx, acc); widx++;
+        return widx;
+    }
 };
 
 // ---------------------------------------------------------------- decoder

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     Encoder<FMT> e;
     e.begin(bts, sink);
     for (uint64_t i = 0; i < np; i++) e.add(bts, a.ts[p0 + i], a.val[p0 + i], sink);
-    uint32_t n = e.finish(sink);
+    if (a.out_nbits) a.out_nbits[s] = e.bits() + (a.no_close ? 0u : 37u);
+    uint32_t n = a.no_close ? e.snapshot(sink) : e.finish(sink);
     a.out_nwords[s] = n;
     if (a.status) a.status[s] = st;
     if (st) atomicOr(a.flags, st);
@@ -384,7 +385,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         GTSC_TICK(tk_comp)
     }
 #undef GTSC_FETCH
-    if (valid) e.finish(sink);
+    if (valid) {
+        if (a.out_nbits) a.out_nbits[s] = e.bits() + (a.no_close ? 0u : 37u);
+        if (a.no_close) e.snapshot(sink); else e.finish(sink);
+    }
     GTSC_FLUSH(true)
 #ifdef GTSC_STAMP
     {
@@ -752,6 +756,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 }
 
 // ------------------------------------------------------------------------
+// Byte images.  ByteBufferBitOutput holds the same bit stream as LongArrayOutput, byte by
+// byte: byte i is bits 8i..8i+7 of the stream, i.e. the words written big-endian
+// (G/ByteBufferBitOutput.java:42-96); after close() the buffer holds floor(N/8)+1 bytes.
+// One wavefront per series.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void words_to_bytes_kernel(uint64_t nseries, const uint64_t* words, Layout wslots,
+                                                             const uint64_t* nbits, uint8_t* bytes, Layout bslots,
+                                                             uint64_t* out_nbytes, uint32_t* flags)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t s = wave; s < nseries; s += nwaves) {
+        const uint64_t* src = words + wslots.begin(s);
+        uint8_t* dst = bytes + bslots.begin(s);
+        const uint64_t n = (nbits[s] >> 3) + 1, cap = bslots.size(s), wcap = wslots.size(s);
+        const uint64_t m = n < cap ? n : cap;
+        for (uint64_t i = lane; i < m; i += 64) {
+            const uint64_t w = (i >> 3) < wcap ? src[i >> 3] : 0;
+            dst[i] = (uint8_t)(w >> (56 - 8 * (i & 7)));
+        }
+        if (lane == 0) {
+            out_nbytes[s] = n;
+            if (n > cap) atomicOr(flags, ST_OVERFLOW);
+        }
+    }
+}
+
+// The word image a LongArrayInput needs for such bytes: the bytes packed big-endian into
+// words, zero-padded, plus the one word of look-ahead the reader loads eagerly
+// (G/LongArrayInput.java:48-52).
+__global__ __launch_bounds__(256) void bytes_to_words_kernel(uint64_t nseries, const uint8_t* bytes, Layout bslots,
+                                                             const uint64_t* nbytes, uint64_t* words, Layout wslots,
+                                                             uint64_t* out_nwords, uint32_t* flags)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t s = wave; s < nseries; s += nwaves) {
+        const uint8_t* src = bytes + bslots.begin(s);
+        uint64_t* dst = words + wslots.begin(s);
+        const uint64_t bcap = bslots.size(s);
+        const uint64_t nb = nbytes ? (nbytes[s] < bcap ? nbytes[s] : bcap) : bcap;
+        const uint64_t n = (nb + 7) / 8 + 1, cap = wslots.size(s);
+        const uint64_t m = n < cap ? n : cap;
+        for (uint64_t i = lane; i < m; i += 64) {
+            uint64_t w = 0;
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint64_t b = 8 * i + k;
+                w = (w << 8) | (b < nb ? src[b] : 0u);
+            }
+            dst[i] = w;
+        }
+        if (lane == 0) {
+            out_nwords[s] = n;
+            if (n > cap) atomicOr(flags, ST_OVERFLOW);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // Compaction: exclusive scan of image lengths, then a wave-per-series copy.
 // ------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
@@ -890,6 +953,28 @@ hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream)
         if (format == FMT_V2) hipLaunchKernelGGL(decode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, a);
         else                  hipLaunchKernelGGL(decode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_words_to_bytes(uint64_t nseries, const uint64_t* words, Layout wslots, const uint64_t* nbits,
+                                 uint8_t* bytes, Layout bslots, uint64_t* out_nbytes, uint32_t* flags, hipStream_t stream)
+{
+    if (nseries == 0) return hipSuccess;
+    uint64_t blocks = (nseries + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(words_to_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, nseries, words, wslots, nbits,
+                       bytes, bslots, out_nbytes, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_bytes_to_words(uint64_t nseries, const uint8_t* bytes, Layout bslots, const uint64_t* nbytes,
+                                 uint64_t* words, Layout wslots, uint64_t* out_nwords, uint32_t* flags, hipStream_t stream)
+{
+    if (nseries == 0) return hipSuccess;
+    uint64_t blocks = (nseries + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(bytes_to_words_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, nseries, bytes, bslots, nbytes,
+                       words, wslots, out_nwords, flags);
     return hipGetLastError();
 }
 

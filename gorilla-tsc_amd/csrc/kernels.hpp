@@ -19,6 +19,8 @@ struct EncodeArgs {
     uint64_t* out_nwords;
     uint32_t* status;    // may be null
     uint32_t* flags;     // one word: OR of all status bits raised
+    uint64_t* out_nbits; // may be null: length of each stream in bits
+    uint32_t no_close;   // nonzero: leave the blocks open (image = snapshot of getLongArray())
 };
 
 struct DecodeArgs {
@@ -41,6 +43,11 @@ hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
 // scan_scratch_words(n) words.
 uint64_t scan_scratch_words(uint64_t n);
 hipError_t launch_exclusive_scan(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* scratch, hipStream_t stream);
+// word images <-> ByteBuffer byte images (big-endian bytes of the same bit stream)
+hipError_t launch_words_to_bytes(uint64_t nseries, const uint64_t* words, Layout wslots, const uint64_t* nbits,
+                                 uint8_t* bytes, Layout bslots, uint64_t* out_nbytes, uint32_t* flags, hipStream_t stream);
+hipError_t launch_bytes_to_words(uint64_t nseries, const uint8_t* bytes, Layout bslots, const uint64_t* nbytes,
+                                 uint64_t* words, Layout wslots, uint64_t* out_nwords, uint32_t* flags, hipStream_t stream);
 hipError_t launch_compact_copy(uint64_t nseries, const uint64_t* slot_words, Layout slots, const uint64_t* nwords,
                                uint64_t* dst, const uint64_t* dst_off, hipStream_t stream);
 

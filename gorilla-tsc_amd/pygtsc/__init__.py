@@ -21,8 +21,10 @@ ST_OVERFLOW, ST_TRUNCATED, ST_MALFORMED = 1, 2, 4
 SYMBOLS = (
     "gtsc_version", "gtsc_last_error", "gtsc_max_words", "gtsc_create", "gtsc_destroy", "gtsc_set_stream",
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
-    "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free",
+    "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
+    "gtsc_bytes_to_words_device",
 )
+ENC_NO_CLOSE = 1
 
 
 class GtscError(RuntimeError):
@@ -65,6 +67,12 @@ def lib():
     L.gtsc_sync.argtypes = [vp]
     L.gtsc_encode_device.restype = i32
     L.gtsc_encode_device.argtypes = [vp, i32, u64, vp, vp, vp, vp, u64, vp, vp, u64, vp, vp]
+    L.gtsc_encode_device_ex.restype = i32
+    L.gtsc_encode_device_ex.argtypes = [vp, i32, C.c_uint32, u64, vp, vp, vp, vp, u64, vp, vp, u64, vp, vp, vp]
+    L.gtsc_words_to_bytes_device.restype = i32
+    L.gtsc_words_to_bytes_device.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp, u64, vp]
+    L.gtsc_bytes_to_words_device.restype = i32
+    L.gtsc_bytes_to_words_device.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp, u64, vp]
     L.gtsc_decode_device.restype = i32
     L.gtsc_decode_device.argtypes = [vp, i32, u64, vp, vp, u64, vp, vp, vp, vp, u64, vp, vp]
     L.gtsc_compact_device.restype = i32
@@ -124,11 +132,28 @@ class Context:
 
     # ---- device-resident -------------------------------------------------
     def encode_device(self, block_ts, ts, val, out_words, out_nwords, pt_off=None, uniform_npoints=0,
-                      out_off=None, uniform_slot_words=0, status=None, fmt=FMT_V2):
+                      out_off=None, uniform_slot_words=0, status=None, fmt=FMT_V2, options=0, out_nbits=None):
         S = block_ts.numel()
+        if options or out_nbits is not None:
+            _check(lib().gtsc_encode_device_ex(self._h, fmt, int(options), S, _dp(block_ts), _dp(ts), _dp(val), _dp(pt_off),
+                                               int(uniform_npoints), _dp(out_words), _dp(out_off), int(uniform_slot_words),
+                                               _dp(out_nwords), _dp(out_nbits), _dp(status)))
+            return
         _check(lib().gtsc_encode_device(self._h, fmt, S, _dp(block_ts), _dp(ts), _dp(val), _dp(pt_off),
                                         int(uniform_npoints), _dp(out_words), _dp(out_off), int(uniform_slot_words),
                                         _dp(out_nwords), _dp(status)))
+
+    def words_to_bytes_device(self, words, nbits, out_bytes, out_nbytes, word_off=None, uniform_slot_words=0,
+                              byte_off=None, uniform_slot_bytes=0):
+        _check(lib().gtsc_words_to_bytes_device(self._h, nbits.numel(), _dp(words), _dp(word_off), int(uniform_slot_words),
+                                                _dp(nbits), _dp(out_bytes), _dp(byte_off), int(uniform_slot_bytes),
+                                                _dp(out_nbytes)))
+
+    def bytes_to_words_device(self, data, out_words, out_nwords, nbytes=None, byte_off=None, uniform_slot_bytes=0,
+                              word_off=None, uniform_slot_words=0):
+        _check(lib().gtsc_bytes_to_words_device(self._h, out_nwords.numel(), _dp(data), _dp(byte_off), int(uniform_slot_bytes),
+                                                _dp(nbytes), _dp(out_words), _dp(word_off), int(uniform_slot_words),
+                                                _dp(out_nwords)))
 
     def decode_device(self, words, ts, val, out_npoints, nseries, in_off=None, uniform_slot_words=0, in_nwords=None,
                       pt_off=None, uniform_capacity=0, status=None, fmt=FMT_V2):

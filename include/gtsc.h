@@ -105,6 +105,54 @@ int gtsc_encode_device(gtsc_ctx *ctx, int format, uint64_t nseries,
                        uint64_t *out_nwords, uint32_t *status);
 
 /*
+ * gtsc_encode_device with two extras:
+ *  - options & GTSC_ENC_NO_CLOSE: the blocks are left open; each image is what
+ *    getLongArray() returns before close(), the completed words plus the current partial
+ *    word (G/LongArrayOutput.java:141-145; the reference's testCopyFlush,
+ *    src/test/java/.../EncodeGorillaTest.java:483-500).  Such an image is not decodable
+ *    (it has no end marker), it is a snapshot of a block still being filled.
+ *  - out_nbits (may be NULL): the length N of each stream in bits, which
+ *    gtsc_words_to_bytes_device needs.
+ */
+#define GTSC_ENC_NO_CLOSE 1u
+int gtsc_encode_device_ex(gtsc_ctx *ctx, int format, uint32_t options, uint64_t nseries,
+                          const int64_t *block_ts,
+                          const int64_t *ts, const uint64_t *val,
+                          const uint64_t *pt_off, uint64_t uniform_npoints,
+                          uint64_t *out_words,
+                          const uint64_t *out_off, uint64_t uniform_slot_words,
+                          uint64_t *out_nwords, uint64_t *out_nbits, uint32_t *status);
+
+/*
+ * Byte images.  ByteBufferBitOutput (G/ByteBufferBitOutput.java:42-103) holds the
+ * same bit stream as LongArrayOutput byte by byte: byte i is stream bits 8i..8i+7, and
+ * after close() the buffer holds floor(N/8)+1 bytes.  gtsc_words_to_bytes_device
+ * writes that image for every series (out_nbytes[s] bytes at out_bytes +
+ * byte_off[s] or + s*uniform_slot_bytes; offsets here are in BYTES) from the word
+ * images and their bit lengths.  gtsc_bytes_to_words_device goes the other way
+ * for input that was stored through a ByteBuffer (ByteBufferBitInput,
+ * G/ByteBufferBitInput.java:20-27): it rebuilds word images, ceil(nbytes/8)+1
+ * words each, that gtsc_decode_device reads.  nbytes may be NULL (whole slot).
+ * The 1.x ByteBufferBitOutput defect that corrupts a bit when a 64-bit value follows a
+ * 5-bit field (G/ByteBufferBitOutput.java:79-83) is not reproduced: bytes are those
+ * of the clean stream.
+ */
+int gtsc_words_to_bytes_device(gtsc_ctx *ctx, uint64_t nseries,
+                               const uint64_t *words,
+                               const uint64_t *word_off, uint64_t uniform_slot_words,
+                               const uint64_t *nbits,
+                               uint8_t *out_bytes,
+                               const uint64_t *byte_off, uint64_t uniform_slot_bytes,
+                               uint64_t *out_nbytes);
+int gtsc_bytes_to_words_device(gtsc_ctx *ctx, uint64_t nseries,
+                               const uint8_t *bytes,
+                               const uint64_t *byte_off, uint64_t uniform_slot_bytes,
+                               const uint64_t *nbytes,
+                               uint64_t *out_words,
+                               const uint64_t *word_off, uint64_t uniform_slot_words,
+                               uint64_t *out_nwords);
+
+/*
  * Decompress nseries images.  Stands in for, per series s:
  *   new GorillaDecompressor(new LongArrayInput(image))          G/GorillaDecompressor.java:23-35
  *   readPair() until null                                       G/GorillaDecompressor.java:42-49

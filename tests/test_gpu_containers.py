@@ -1,0 +1,109 @@
+"""Snapshots of open blocks and ByteBuffer byte images on the GPU, against the oracle
+(T/EncodeGorillaTest.java:483-500 testCopyFlush; G/ByteBufferBitOutput.java:42-103)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import pyoracle as O  # noqa: E402
+import pygtsc as G  # noqa: E402
+from pygtsc import synth  # noqa: E402
+
+FMTS = [(G.FMT_V2, O.V2), (G.FMT_V1, O.V1)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = G.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+
+
+def batch():
+    b = synth.ragged_mix(seed=21, nseries=150, pmax=180)
+    # word-boundary cases: a few constant series of growing length walk the stream end across a word edge
+    return b
+
+
+def encode(ctx, b, gfmt, options):
+    S = b.nseries
+    lens = np.diff(b.pt_off.astype(np.int64))
+    slot = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum([G.max_words(int(p)) for p in lens], out=slot[1:])
+    d_out = torch.full((int(slot[-1]),), -1, dtype=torch.int64, device="cuda")
+    d_nw = torch.zeros(S, dtype=torch.int64, device="cuda")
+    d_nb = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_device(dev(b.block_ts), dev(b.ts), dev(b.val), d_out, d_nw, pt_off=dev(b.pt_off), out_off=dev(slot),
+                      fmt=gfmt, options=options, out_nbits=d_nb)
+    ctx.sync()
+    return d_out, d_nw, d_nb, slot
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_snapshot_of_open_blocks(ctx, gfmt, ofmt):
+    b = batch()
+    d_out, d_nw, d_nb, slot = encode(ctx, b, gfmt, G.ENC_NO_CLOSE)
+    out, nw, nb = d_out.cpu().numpy().view(np.uint64), d_nw.cpu().numpy(), d_nb.cpu().numpy()
+    for s in range(b.nseries):
+        t, v = b.series(s)
+        e = O.Encoder(int(b.block_ts[s]), ofmt)
+        for ti, vi in zip(t.tolist(), v.tolist()):
+            e.add(ti, vi)
+        ref = e.words()  # not closed
+        assert int(nb[s]) == e.nbits
+        assert int(nw[s]) == len(ref)
+        assert np.array_equal(out[int(slot[s]):int(slot[s]) + len(ref)], ref), s
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_byte_images_and_back(ctx, gfmt, ofmt):
+    b = batch()
+    S = b.nseries
+    d_out, d_nw, d_nb, slot = encode(ctx, b, gfmt, 0)
+    nb = d_nb.cpu().numpy()
+    boff = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum(nb // 8 + 1, out=boff[1:])  # back to back, at odd byte offsets
+    d_bytes = torch.full((int(boff[-1]) + 8,), 0x5A, dtype=torch.uint8, device="cuda")
+    d_nby = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.words_to_bytes_device(d_out, d_nb, d_bytes, d_nby, word_off=dev(slot), byte_off=dev(boff))
+    ctx.sync()
+    got = d_bytes.cpu().numpy()
+    nby = d_nby.cpu().numpy()
+    for s in range(S):
+        t, v = b.series(s)
+        e = O.Encoder(int(b.block_ts[s]), ofmt)
+        for ti, vi in zip(t.tolist(), v.tolist()):
+            e.add(ti, vi)
+        e.close()
+        ref = np.frombuffer(e.bytes(), dtype=np.uint8)
+        assert int(nb[s]) == e.nbits and int(nby[s]) == len(ref)
+        assert np.array_equal(got[int(boff[s]):int(boff[s + 1])], ref), s
+    assert np.all(got[int(boff[-1]):] == 0x5A)  # nothing written past the last image
+    # bytes -> word images -> decode gives the points back
+    woff = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum((nby + 7) // 8 + 1, out=woff[1:])
+    d_w = torch.full((int(woff[-1]),), -1, dtype=torch.int64, device="cuda")
+    d_nw2 = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.bytes_to_words_device(d_bytes, d_w, d_nw2, nbytes=d_nby, byte_off=dev(boff), word_off=dev(woff))
+    d_ts = torch.zeros(b.npoints, dtype=torch.int64, device="cuda")
+    d_val = torch.zeros(b.npoints, dtype=torch.int64, device="cuda")
+    d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.decode_device(d_w, d_ts, d_val, d_np, S, in_off=dev(woff), in_nwords=d_nw2, pt_off=dev(b.pt_off), fmt=gfmt)
+    ctx.sync()
+    assert np.array_equal(d_np.cpu().numpy(), np.diff(b.pt_off.astype(np.int64)))
+    rts, rval, rnp, rst = O.decode_batch(d_w.cpu().numpy().view(np.uint64), woff, d_nw2.cpu().numpy().view(np.uint64),
+                                         b.pt_off, fmt=ofmt)
+    assert np.array_equal(d_ts.cpu().numpy(), rts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), rval)
+    if gfmt == G.FMT_V2:
+        assert np.array_equal(d_ts.cpu().numpy(), b.ts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), b.val)
