@@ -542,6 +542,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 
     // ---- top-up state: the lane's load in flight between two checks
     bool pend = false;
+    uint32_t dense = 0;  // wave-uniform: > 0 after a lane outran its top-ups: the rings are then looked after at every point for a while
     U4 tq;  // defined whenever pend is set
     uint32_t tback = 0;
 #define GTSC_TOPUP_LAND()                                                                      \
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             for (;;) {                                                                         \
                 const bool shortw = active && filled < nw && d.widx + 2 >= filled;             \
                 if (!__any(shortw)) break;                                                     \
+                dense = 3;                                                                     \
                 if (shortw) {                                                                  \
                     if (!pend) GTSC_TOPUP_ISSUE()                                              \
                     GTSC_TOPUP_LAND()                                                          \
@@ -655,11 +657,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         ts_ref = (uint32_t)(d.stored_ts >> 32);
         n0 = n;
         dmask = 0;
+        if (dense) dense--;
 #pragma unroll 1
         for (uint32_t k2 = 0; k2 < DCH / 2; k2++) {
             const uint32_t ad = tile_addr(lane, k2);
             const uint32_t adt = dec_ts_addr(lane, 2 * k2);
             GTSC_POINT(0)
+            if (dense) {  // a stream this dense needs a top-up per point to keep up (2 words per point at most)
+                if (__any(pend)) { if (pend) GTSC_TOPUP_LAND() }
+                const bool low0 = d.widx >= limit;
+                if (__any(low0)) { if (low0) GTSC_TOPUP_ISSUE() }
+            }
             GTSC_POINT(1)
             if (__any(pend)) { if (pend) GTSC_TOPUP_LAND() }
             const bool low = d.widx >= limit;
