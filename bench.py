@@ -86,6 +86,13 @@ def cpu_baseline(block, ts, val, P, sample_series, threads):
         best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
     assert np.array_equal(dt, t) and np.array_equal(dv, v)
     raw = 16.0 * S * P
+    # one thread on a sixteenth of the sample, for comparison with single-thread figures of other codecs
+    S1 = max(S // 16, 1)
+    t0 = time.perf_counter()
+    o1, f1, n1, _ = O.encode_batch(b[:S1], t[: S1 * P], v[: S1 * P], pt_off[: S1 + 1], nthreads=1)
+    t1 = time.perf_counter()
+    O.decode_batch(o1, f1, n1, pt_off[: S1 + 1], nthreads=1)
+    t2 = time.perf_counter()
     return {
         "value": round(2 * raw / (best_e + best_d) / 1e9, 3),
         "unit": "GB/s",
@@ -94,6 +101,8 @@ def cpu_baseline(block, ts, val, P, sample_series, threads):
         "sample": "%d series x %d points (%.0f MB raw), compress+decompress, best of 2" % (S, P, raw / 1e6),
         "compress_GBps": round(raw / best_e / 1e9, 3),
         "decompress_GBps": round(raw / best_d / 1e9, 3),
+        "one_thread_compress_Mpoints_per_s": round(S1 * P / (t1 - t0) / 1e6, 1),
+        "one_thread_decompress_Mpoints_per_s": round(S1 * P / (t2 - t1) / 1e6, 1),
     }
 
 
@@ -120,8 +129,10 @@ def main():
     ap.add_argument("--series", type=int, default=1_000_000)
     ap.add_argument("--points", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-series", type=int, default=262144)
+    ap.add_argument("--cpu-sample-series", type=int, default=1_000_000)
     ap.add_argument("--slot-words", type=int, default=0, help="words per output slot (default: the worst case for --points)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-verify", action="store_true", help="skip the round-trip check (kernel experiments only)")
     args = ap.parse_args()
 
@@ -131,12 +142,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    dev_index = local_rank % ndev  # more ranks than GPUs only in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
+    red_device = device if args.backend == "nccl" else None  # where the timing reduction's tensor lives
 
     S, P = args.series, args.points
     block, ts, val = make_workload(args.workload, S, P, device, 0x5EED0002 + rank)
@@ -147,7 +166,7 @@ def main():
     val2 = torch.zeros_like(val)
     npts = torch.zeros(S, dtype=torch.int64, device=device)
 
-    ctx = G.Context(local_rank)
+    ctx = G.Context(dev_index)
     stream = torch.cuda.Stream(device=device)
     ctx.set_stream(stream.cuda_stream)
 
@@ -193,7 +212,7 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dist, device)
+    elapsed = shard.max_over_ranks(elapsed, dist, red_device)
 
     enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
