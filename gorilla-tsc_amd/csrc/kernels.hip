@@ -12,6 +12,11 @@
 #include "codec_device.hpp"
 #include "kernels.hpp"
 
+// Measurement switches, never set in the shipped library:
+//   -DGTSC_STAMP        per-wave cycle stamps (s_memtime) left in the outputs, read by tools/stamps.py
+//   -DGTSC_ABLATE=n     leaves one cost out to see what it is worth (1/3: encoder arithmetic, 4: decoder
+//                       stores, 5: decoder tile writes, 6: decoder ring reads, 7: both); results are wrong
+//   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy
 #ifndef GTSC_ABLATE
 #define GTSC_ABLATE 0
 #endif
