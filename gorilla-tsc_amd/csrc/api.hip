@@ -285,7 +285,7 @@ void gtsc_host_free(void* p)
 
 namespace {
 
-constexpr uint64_t CHUNK_POINTS = 16ull << 20;  // 256 MiB of raw points per chunk
+constexpr uint64_t CHUNK_POINTS = 64ull << 20;  // 1 GiB of raw points per chunk
 constexpr uint64_t CHUNK_SERIES = 4ull << 20;
 
 struct Chunk { uint64_t s0, s1; };
