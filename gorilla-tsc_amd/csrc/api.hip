@@ -288,6 +288,17 @@ namespace {
 constexpr uint64_t CHUNK_POINTS = 64ull << 20;  // 1 GiB of raw points per chunk
 constexpr uint64_t CHUNK_SERIES = 4ull << 20;
 
+// Chunk size in points; GTSC_CHUNK_POINTS overrides it (tests use it to get many chunks from a small batch).
+uint64_t chunk_points()
+{
+    static const uint64_t v = [] {
+        const char* e = getenv("GTSC_CHUNK_POINTS");
+        const uint64_t n = e ? strtoull(e, nullptr, 10) : 0;
+        return n ? (n < CHUNK_POINTS ? n : CHUNK_POINTS) : CHUNK_POINTS;
+    }();
+    return v;
+}
+
 struct Chunk { uint64_t s0, s1; };
 
 // cut [0, nseries) into runs of whole series of at most CHUNK_POINTS points
@@ -299,7 +310,7 @@ std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t u
         uint64_t e = s, pts = 0;
         while (e < nseries && e - s < CHUNK_SERIES) {
             const uint64_t n = off ? off[e + 1] - off[e] : uniform;
-            if (e > s && pts + n > CHUNK_POINTS) break;
+            if (e > s && pts + n > chunk_points()) break;
             pts += n;
             e++;
         }

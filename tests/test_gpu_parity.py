@@ -360,6 +360,18 @@ def test_host_entry_points(ctx):
     assert ei.value.code == G.ERR_CAPACITY
 
 
+def test_host_entry_points_many_chunks():
+    """The chunked two-stream pipeline with chunks of a few thousand points (own process: the chunk
+    size is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GTSC_CHUNK_POINTS="3000")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_chunks_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_full_size_1m_series_round_trip(ctx):
     """BASELINE config: 1M series x 120 points.  Too big for a word-by-word oracle
     comparison in test time, so: (a) decode(encode(x)) == x on the device for all
