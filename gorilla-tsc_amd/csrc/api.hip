@@ -59,6 +59,10 @@ struct gtsc_ctx {
     uint32_t* d_flags = nullptr;    // OR of status bits raised since the last sync
     uint32_t* h_flags = nullptr;    // pinned mirror
     DeviceBuf scan_scratch;
+    // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
+    int predictor = GTSC_PRED_LAST;
+    uint32_t dfcm_mask = 0;
+    DeviceBuf dfcm_tables[3];  // device entry points, host stage 0, host stage 1
     // staging for the host entry points, two sets for double buffering
     struct Stage {
         hipStream_t stream = nullptr;
@@ -86,6 +90,20 @@ int check_ctx(gtsc_ctx* ctx)
 }
 
 }  // namespace
+
+// Zero-filled DFCM tables for nseries blocks in buffer `which`, on `stream`; null when the context
+// uses the last-value predictor.  (G/predictors/DifferentialFCM.java:23-33: new long[size], hash 0.)
+static hipError_t dfcm_prepare(gtsc_ctx* c, int which, uint64_t nseries, hipStream_t stream, int64_t** tables)
+{
+    *tables = nullptr;
+    if (c->predictor != GTSC_PRED_DFCM || nseries == 0) return hipSuccess;
+    const size_t bytes = (size_t)nseries * ((size_t)c->dfcm_mask + 1) * sizeof(int64_t);
+    DeviceBuf& b = c->dfcm_tables[which];
+    if (hipError_t e = b.reserve(bytes)) return e;
+    if (hipError_t e = hipMemsetAsync(b.p, 0, bytes, stream)) return e;
+    *tables = b.as<int64_t>();
+    return hipSuccess;
+}
 
 // true when any of the given (possibly NULL) pointers is not 8-byte aligned
 template <typename... P>
@@ -146,10 +164,29 @@ int gtsc_destroy(gtsc_ctx* c)
             b->release();
     }
     c->scan_scratch.release();
+    for (DeviceBuf& b : c->dfcm_tables) b.release();
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+    return GTSC_OK;
+}
+
+int gtsc_set_predictor(gtsc_ctx* c, int predictor, int table_size)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (predictor == GTSC_PRED_LAST) {
+        c->predictor = GTSC_PRED_LAST;
+        c->dfcm_mask = 0;
+        return GTSC_OK;
+    }
+    if (predictor != GTSC_PRED_DFCM) return fail(GTSC_ERR_ARG, "unknown predictor %d", predictor);
+    if (table_size <= 0) return fail(GTSC_ERR_ARG, "table size must be positive");  // IllegalArgumentException in Java
+    // rounded up to a power of two: 1 << (64 - numberOfLeadingZeros(size - 1))
+    const uint64_t s1 = (uint64_t)table_size - 1;
+    const int lz = s1 ? __builtin_clzll(s1) : 64;
+    c->predictor = GTSC_PRED_DFCM;
+    c->dfcm_mask = (uint32_t)((1ull << (64 - lz)) - 1);
     return GTSC_OK;
 }
 
@@ -187,9 +224,13 @@ int gtsc_encode_device_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t ns
     if (misaligned8(block_ts, ts, val, pt_off, out_words, out_off, out_nwords, out_nbits))
         return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
     if (!out_off && uniform_slot_words < 3) return fail(GTSC_ERR_ARG, "uniform_slot_words must be at least 3 (an empty block)");
+    if (c->predictor != GTSC_PRED_LAST && format != GTSC_FMT_V2)
+        return fail(GTSC_ERR_ARG, "only the 2.x format takes a predictor");
     DeviceGuard g(c->device);
+    int64_t* tables = nullptr;
+    HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
-                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u};
+                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, tables, c->dfcm_mask};
     HIP_TRY(launch_encode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -241,9 +282,13 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     if ((!ts || !val) && (pt_off || uniform_capacity)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
     if (misaligned8(words, in_off, in_nwords, ts, val, pt_off, out_npoints))
         return fail(GTSC_ERR_ARG, "64-bit arrays must be 8-byte aligned");
+    if (c->predictor != GTSC_PRED_LAST && format != GTSC_FMT_V2)
+        return fail(GTSC_ERR_ARG, "only the 2.x format takes a predictor");
     DeviceGuard g(c->device);
+    int64_t* tables = nullptr;
+    HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
-                 out_npoints, status, c->d_flags};
+                 out_npoints, status, c->d_flags, tables, c->dfcm_mask};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -421,7 +466,8 @@ int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* b
         }
         EncodeArgs a{ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
                      Layout{d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot},
-                     st.nwords.as<uint64_t>(), nullptr, c->d_flags, nullptr, 0u};
+                     st.nwords.as<uint64_t>(), nullptr, c->d_flags, nullptr, 0u, nullptr, c->dfcm_mask};
+        HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_encode(a, format, st.stream));
         uint64_t* scratch = c->scan_scratch.as<uint64_t>() + (size_t)b * scan_scratch_words(CHUNK_SERIES);
         HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), ns, st.coff.as<uint64_t>(), scratch, st.stream));
@@ -485,7 +531,8 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, st.stream));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
-                     st.status.as<uint32_t>(), c->d_flags};
+                     st.status.as<uint32_t>(), c->d_flags, nullptr, c->dfcm_mask};
+        HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, st.stream));
         if (np) {
             HIP_TRY(hipMemcpyAsync(ts + p0, st.ts.p, np * 8, hipMemcpyDeviceToHost, st.stream));

@@ -37,6 +37,25 @@ struct Layout {
 __device__ __forceinline__ uint32_t clz64(uint64_t x) { return (uint32_t)__builtin_clzll(x); }  // x != 0
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }  // x != 0
 
+// ---------------------------------------------------------------- predictors
+// PRED_LAST: the prediction is the previous value (G/predictors/LastValuePredictor.java:10-22).
+// PRED_DFCM: differential finite context method (G/predictors/DifferentialFCM.java:23-46): a table
+// of value differences indexed by a hash of recent differences; the table of a series lives in
+// global memory (2^k entries, zero-filled before the block starts).
+constexpr int PRED_LAST = 0, PRED_DFCM = 1;
+struct Dfcm {
+    int64_t* table;
+    uint32_t hash, mask;
+    __device__ __forceinline__ uint64_t predict(uint64_t last) const { return (uint64_t)table[hash] + last; }
+    __device__ __forceinline__ void update(uint64_t last, uint64_t v)
+    {
+        const int64_t d = (int64_t)(v - last);
+        table[hash] = d;
+        // (int)(((lastHash << 5) ^ ((value - lastValue) >> 50)) & mask): the mask keeps low bits only
+        hash = ((hash << 5) ^ (uint32_t)(d >> 50)) & mask;
+    }
+};
+
 // ---------------------------------------------------------------- encoder
 // Pending bits sit left-aligned in `acc` (its top `nacc` bits, zeros below).
 // A completed 64-bit word is handed to the sink: sink(word_index, word).
@@ -45,8 +64,9 @@ __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__built
 // branchy form pays for every path anyway plus the exec-mask bookkeeping.
 // put() keeps the dependency chain through `acc` to an OR and a select: the
 // shifts depend only on the bit count, which runs ahead as a chain of adds.
-template <int FMT>
+template <int FMT, int PRED = PRED_LAST>
 struct Encoder {
+    Dfcm dfcm;  // PRED_DFCM only
     uint64_t acc;
     uint32_t nacc;
     uint32_t widx;
@@ -89,6 +109,7 @@ struct Encoder {
         stored_delta = (FMT == FMT_V2) ? (int64_t)(int32_t)(uint32_t)d : (int64_t)d;
         pts_lo = ts_lo; pts_hi = ts_hi;
         started = !ts_zero;
+        if (PRED == PRED_DFCM) dfcm.update(prev, v);  // writeFirst: predictor.update(value), G/ValueCompressor.java:27-30
         prev = v;
         put(d & 0x7FFFFFFull, 27, sink);
         put(v, 64, sink);
@@ -157,7 +178,8 @@ struct Encoder {
         }
         pts_lo = ts_lo; pts_hi = ts_hi;
         // ---- value: header vh of vhlen bits, payload pay of plen bits
-        const uint64_t x = prev ^ v;
+        const uint64_t x = (PRED == PRED_DFCM ? dfcm.predict(prev) : prev) ^ v;  // G/ValueCompressor.java:32-34
+        if (PRED == PRED_DFCM) dfcm.update(prev, v);
         prev = v;
         const bool nz = x != 0;
         uint32_t lz = (uint32_t)__clzll((long long)x);         // 64 when x == 0 (unused then)
@@ -211,8 +233,9 @@ struct Encoder {
 // before the following point.  All fields of a point are extracted speculatively
 // with selects; the rare outcomes (end of stream, truncation, malformed) share
 // one branch.
-template <int FMT>
+template <int FMT, int PRED = PRED_LAST>
 struct Decoder {
+    Dfcm dfcm;  // PRED_DFCM only
     uint64_t r0, r1, r2, r3;
     uint32_t widx, off, nwords;
     uint32_t st;
@@ -275,6 +298,7 @@ struct Decoder {
             if (d == 0x7FFFFFFu) return false;  // empty block
             const uint64_t v = peek_at(off + 27);
             if (runs_off(off + 91)) { st |= ST_TRUNCATED; return false; }
+            if (PRED == PRED_DFCM) dfcm.update(val, v);  // readFirst: predictor.update(value), G/ValueDecompressor.java:26-30
             val = v;
             advance(off + 91, src);
             stored_delta = (int64_t)d;
@@ -338,7 +362,12 @@ struct Decoder {
         }
         lead = nlead;
         trail = ntrail;
-        val ^= bits << ((uint32_t)ntrail & 63u);  // Java shifts by the count mod 64
+        {
+            const uint64_t x = bits << ((uint32_t)ntrail & 63u);  // Java shifts by the count mod 64
+            const uint64_t v = (PRED == PRED_DFCM ? dfcm.predict(val) : val) ^ x;  // G/ValueDecompressor.java:32-54
+            if (PRED == PRED_DFCM) dfcm.update(val, v);
+            val = v;
+        }
         stored_delta = (int64_t)((uint64_t)stored_delta + (uint64_t)dd);
         stored_ts += (uint64_t)stored_delta;
         advance(o3, src);

@@ -35,7 +35,7 @@ struct GlobalSink {
     __device__ __forceinline__ void operator()(uint32_t i, uint64_t w) const { if (i < cap) out[i] = w; else *st = ST_OVERFLOW; }
 };
 
-template <int FMT>
+template <int FMT, int PRED = PRED_LAST>
 __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
 {
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     const int64_t bts = a.block_ts[s];
     uint32_t st = 0;
     GlobalSink sink{out, cap, &st};
-    Encoder<FMT> e;
+    Encoder<FMT, PRED> e;
     e.begin(bts, sink);
+    if (PRED == PRED_DFCM) e.dfcm = Dfcm{a.dfcm_tables + s * ((uint64_t)a.dfcm_mask + 1), 0u, a.dfcm_mask};
     for (uint64_t i = 0; i < np; i++) e.add(bts, a.ts[p0 + i], a.val[p0 + i], sink);
     if (a.out_nbits) a.out_nbits[s] = e.bits() + (a.no_close ? 0u : 37u);
     uint32_t n = a.no_close ? e.snapshot(sink) : e.finish(sink);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     if (st) atomicOr(a.flags, st);
 }
 
-template <int FMT>
+template <int FMT, int PRED = PRED_LAST>
 __global__ __launch_bounds__(256) void decode_direct_kernel(DecodeArgs a)
 {
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(256) void decode_direct_kernel(DecodeArgs a)
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
     const uint64_t p0 = a.pts.begin(s), cap = a.pts.size(s);
     auto src = [&](uint32_t i) -> uint64_t { return i < nw ? in[i] : 0ull; };
-    Decoder<FMT> d;
+    Decoder<FMT, PRED> d;
     d.begin(nw, src);
+    if (PRED == PRED_DFCM) d.dfcm = Dfcm{a.dfcm_tables + s * ((uint64_t)a.dfcm_mask + 1), 0u, a.dfcm_mask};
     uint64_t n = 0;
     uint32_t st = 0;
     int64_t t; uint64_t v;
@@ -942,7 +944,11 @@ static bool use_direct_kernels()
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
 {
     if (a.nseries == 0) return hipSuccess;
-    if (use_direct_kernels()) {
+    if (a.dfcm_tables) {  // the table look-ups are per-lane global accesses anyway: direct form only
+        if (format != FMT_V2) return hipErrorInvalidValue;
+        const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
+        hipLaunchKernelGGL((encode_direct_kernel<FMT_V2, PRED_DFCM>), dim3(blocks), dim3(256), 0, stream, a);
+    } else if (use_direct_kernels()) {
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
@@ -957,7 +963,11 @@ hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
 hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream)
 {
     if (a.nseries == 0) return hipSuccess;
-    if (use_direct_kernels()) {
+    if (a.dfcm_tables) {
+        if (format != FMT_V2) return hipErrorInvalidValue;
+        const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
+        hipLaunchKernelGGL((decode_direct_kernel<FMT_V2, PRED_DFCM>), dim3(blocks), dim3(256), 0, stream, a);
+    } else if (use_direct_kernels()) {
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(decode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(decode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);

@@ -21,6 +21,8 @@ struct EncodeArgs {
     uint32_t* flags;     // one word: OR of all status bits raised
     uint64_t* out_nbits; // may be null: length of each stream in bits
     uint32_t no_close;   // nonzero: leave the blocks open (image = snapshot of getLongArray())
+    int64_t* dfcm_tables;  // DFCM predictor: nseries zero-filled tables of dfcm_mask + 1 entries; null = last-value predictor
+    uint32_t dfcm_mask;
 };
 
 struct DecodeArgs {
@@ -34,6 +36,8 @@ struct DecodeArgs {
     uint64_t* out_npoints;
     uint32_t* status;         // may be null
     uint32_t* flags;
+    int64_t* dfcm_tables;     // as in EncodeArgs
+    uint32_t dfcm_mask;
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);

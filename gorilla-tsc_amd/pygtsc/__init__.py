@@ -22,8 +22,9 @@ SYMBOLS = (
     "gtsc_version", "gtsc_last_error", "gtsc_max_words", "gtsc_create", "gtsc_destroy", "gtsc_set_stream",
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
     "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
-    "gtsc_bytes_to_words_device",
+    "gtsc_bytes_to_words_device", "gtsc_set_predictor",
 )
+PRED_LAST, PRED_DFCM = 0, 1
 ENC_NO_CLOSE = 1
 
 
@@ -63,6 +64,8 @@ def lib():
     L.gtsc_destroy.argtypes = [vp]
     L.gtsc_set_stream.restype = i32
     L.gtsc_set_stream.argtypes = [vp, vp]
+    L.gtsc_set_predictor.restype = i32
+    L.gtsc_set_predictor.argtypes = [vp, i32, i32]
     L.gtsc_sync.restype = i32
     L.gtsc_sync.argtypes = [vp]
     L.gtsc_encode_device.restype = i32
@@ -126,6 +129,9 @@ class Context:
 
     def set_stream(self, hip_stream):
         _check(lib().gtsc_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_predictor(self, predictor, table_size=0):
+        _check(lib().gtsc_set_predictor(self._h, int(predictor), int(table_size)))
 
     def sync(self):
         _check(lib().gtsc_sync(self._h))

@@ -77,6 +77,21 @@ uint64_t gtsc_max_words(uint64_t npoints);
 int gtsc_create(int device_id, gtsc_ctx **ctx);
 int gtsc_destroy(gtsc_ctx *ctx);
 
+/*
+ * Predictor of the value codec for the calls that follow on this context (2.x format
+ * only): the third constructor argument of GorillaCompressor / second of
+ * GorillaDecompressor (G/GorillaCompressor.java:34-37, G/GorillaDecompressor.java:27-31).
+ * GTSC_PRED_LAST is LastValuePredictor (the default; table_size ignored).
+ * GTSC_PRED_DFCM is DifferentialFCM(table_size) (G/predictors/DifferentialFCM.java:23-46):
+ * table_size > 0 is rounded up to a power of two as the Java constructor does; the library
+ * keeps one table per block in device memory (nseries * size * 8 bytes per call).  Blocks
+ * coded with a predictor must be decoded with the same one.  DFCM runs on the plain
+ * lane-per-series kernels (its table look-ups are per-lane memory accesses).
+ */
+#define GTSC_PRED_LAST 0
+#define GTSC_PRED_DFCM 1
+int gtsc_set_predictor(gtsc_ctx *ctx, int predictor, int table_size);
+
 /* Enqueue on a caller-owned hipStream_t instead of the context's own
  * (NULL restores the context's stream). */
 int gtsc_set_stream(gtsc_ctx *ctx, void *hip_stream);

@@ -107,3 +107,50 @@ def test_byte_images_and_back(ctx, gfmt, ofmt):
     assert np.array_equal(d_ts.cpu().numpy(), rts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), rval)
     if gfmt == G.FMT_V2:
         assert np.array_equal(d_ts.cpu().numpy(), b.ts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), b.val)
+
+
+@pytest.mark.parametrize("size", [1, 5, 128, 1024])
+def test_dfcm_predictor(ctx, size):
+    """GorillaCompressor(ts, out, new DifferentialFCM(size)) per block (G/GorillaCompressor.java:34-37),
+    checked word for word against the oracle's DFCM; decoding needs the same predictor."""
+    b = synth.ragged_mix(seed=31, nseries=130, pmax=260)
+    S = b.nseries
+    lens = np.diff(b.pt_off.astype(np.int64))
+    slot = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum([G.max_words(int(p)) for p in lens], out=slot[1:])
+    d_out = torch.full((int(slot[-1]),), -1, dtype=torch.int64, device="cuda")
+    d_nw = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.set_predictor(G.PRED_DFCM, size)
+    try:
+        ctx.encode_device(dev(b.block_ts), dev(b.ts), dev(b.val), d_out, d_nw, pt_off=dev(b.pt_off), out_off=dev(slot))
+        ctx.sync()
+        out, nw = d_out.cpu().numpy().view(np.uint64), d_nw.cpu().numpy()
+        differs_from_last_value = False
+        for s in range(S):
+            t, v = b.series(s)
+            ref = O.encode_block(int(b.block_ts[s]), t, v, O.V2, dfcm_size=size)
+            assert int(nw[s]) == len(ref) and np.array_equal(out[int(slot[s]):int(slot[s]) + len(ref)], ref), s
+            plain = O.encode_block(int(b.block_ts[s]), t, v, O.V2)
+            differs_from_last_value |= len(plain) != len(ref) or not np.array_equal(plain, ref)
+        assert differs_from_last_value  # the predictor did take part
+        d_ts = torch.zeros(b.npoints, dtype=torch.int64, device="cuda")
+        d_val = torch.zeros(b.npoints, dtype=torch.int64, device="cuda")
+        d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.decode_device(d_out, d_ts, d_val, d_np, S, in_off=dev(slot), in_nwords=d_nw, pt_off=dev(b.pt_off))
+        ctx.sync()
+        assert np.array_equal(d_np.cpu().numpy(), lens)
+        assert np.array_equal(d_ts.cpu().numpy(), b.ts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), b.val)
+        # host entry points use the same predictor
+        words, off = ctx.encode_host(b.block_ts, b.ts, b.val, pt_off=b.pt_off)
+        ts, val, npts, st = ctx.decode_host(words, off, pt_off=b.pt_off)
+        assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+        s0 = 7
+        ref = O.encode_block(int(b.block_ts[s0]), *b.series(s0), O.V2, dfcm_size=size)
+        assert np.array_equal(words[int(off[s0]):int(off[s0 + 1])], ref)
+        with pytest.raises(G.GtscError):  # the 1.x classes take no predictor
+            ctx.encode_device(dev(b.block_ts), dev(b.ts), dev(b.val), d_out, d_nw, pt_off=dev(b.pt_off), out_off=dev(slot),
+                              fmt=G.FMT_V1)
+    finally:
+        ctx.set_predictor(G.PRED_LAST)
