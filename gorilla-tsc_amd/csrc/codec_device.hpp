@@ -149,31 +149,40 @@ struct Encoder {
             // int arithmetic: only the low 32 bits of the timestamps take part
             const uint32_t nd = ts_lo - pts_lo;
             const int32_t dod = (int32_t)(nd - (uint32_t)(int32_t)stored_delta);
-            const uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
-            uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0 (dod == -1)
-            need = need > 13u ? 13u : need;
-            // bucket by bits required, two bits per entry: 0 -> 36-bit code (need 0 or > 12),
-            // 1 -> '10'+7, 2 -> '110'+9, 3 -> '1110'+12   (G/GorillaCompressor.java:110-137)
-            constexpr uint32_t BUCKET = (1u * 0x5554u) | (2u << 16) | (2u << 18) | (3u << 20) | (3u << 22) | (3u << 24);
-            const uint32_t bk = (BUCKET >> (2u * need)) & 3u;
-            constexpr uint32_t LEN = 36u | (9u << 8) | (12u << 16) | (16u << 24);
-            constexpr uint64_t PRE = 0ull | (0x100ull << 16) | (0xC00ull << 32) | (0xE000ull << 48);
-            const bool zero = dod == 0;
-            tlen = zero ? 1u : (LEN >> (8u * bk)) & 0xFFu;
-            const uint32_t pre = (uint32_t)(PRE >> (16u * bk)) & 0xFFFFu;
-            tlo = zero ? 0u : (z | pre);
-            thi = (zero || bk != 0) ? 0u : 0xFu;
+            if (__all(dod == 0)) {
+                // regular cadence in every lane (the common case by far): the code is the single bit '0'
+                tlen = 1u; tlo = 0u; thi = 0u;
+            } else {
+                const uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
+                uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0 (dod == -1)
+                need = need > 13u ? 13u : need;
+                // bucket by bits required, two bits per entry: 0 -> 36-bit code (need 0 or > 12),
+                // 1 -> '10'+7, 2 -> '110'+9, 3 -> '1110'+12   (G/GorillaCompressor.java:110-137)
+                constexpr uint32_t BUCKET = (1u * 0x5554u) | (2u << 16) | (2u << 18) | (3u << 20) | (3u << 22) | (3u << 24);
+                const uint32_t bk = (BUCKET >> (2u * need)) & 3u;
+                constexpr uint32_t LEN = 36u | (9u << 8) | (12u << 16) | (16u << 24);
+                constexpr uint64_t PRE = 0ull | (0x100ull << 16) | (0xC00ull << 32) | (0xE000ull << 48);
+                const bool zero = dod == 0;
+                tlen = zero ? 1u : (LEN >> (8u * bk)) & 0xFFu;
+                const uint32_t pre = (uint32_t)(PRE >> (16u * bk)) & 0xFFFFu;
+                tlo = zero ? 0u : (z | pre);
+                thi = (zero || bk != 0) ? 0u : 0xFu;
+            }
             stored_delta = (int64_t)(int32_t)nd;
         } else {
             const uint64_t ts = ((uint64_t)ts_hi << 32) | ts_lo, pts = ((uint64_t)pts_hi << 32) | pts_lo;
             const uint64_t nd = ts - pts;
             const uint64_t dod = nd - (uint64_t)stored_delta;
-            const bool zero = dod == 0;
-            const bool b7 = (dod + 63u) <= 127u, b9 = (dod + 255u) <= 511u, b12 = (dod + 2047u) <= 4095u;
-            tlen = zero ? 1u : b7 ? 9u : b9 ? 12u : b12 ? 16u : 36u;
-            const uint32_t lo = (uint32_t)dod;
-            tlo = zero ? 0u : b7 ? (0x100u | (lo & 0x7Fu)) : b9 ? (0xC00u | (lo & 0x1FFu)) : b12 ? (0xE000u | (lo & 0xFFFu)) : lo;
-            thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
+            if (__all(dod == 0)) {
+                tlen = 1u; tlo = 0u; thi = 0u;  // regular cadence in every lane
+            } else {
+                const bool zero = dod == 0;
+                const bool b7 = (dod + 63u) <= 127u, b9 = (dod + 255u) <= 511u, b12 = (dod + 2047u) <= 4095u;
+                tlen = zero ? 1u : b7 ? 9u : b9 ? 12u : b12 ? 16u : 36u;
+                const uint32_t lo = (uint32_t)dod;
+                tlo = zero ? 0u : b7 ? (0x100u | (lo & 0x7Fu)) : b9 ? (0xC00u | (lo & 0x1FFu)) : b12 ? (0xE000u | (lo & 0xFFFu)) : lo;
+                thi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
+            }
             stored_delta = (int64_t)nd;
         }
         pts_lo = ts_lo; pts_hi = ts_hi;
@@ -420,9 +429,18 @@ struct WindowDecoder {
     };
 
     // Branch-free parse of an ordinary point from 128 bits of stream (hi,lo) at the current position.
+    // TS_ZERO: the caller has seen that the timestamp code is the single bit '0' (regular
+    // cadence, the common case by far), so that part folds away.
+    template <bool TS_ZERO = false>
     __device__ __forceinline__ Parsed parse(uint64_t hi, uint64_t lo) const
     {
         Parsed p;
+        if (TS_ZERO) {
+            p.eos = false;
+            p.dd = 0;
+            parse_value(p, hi, lo, 1u);
+            return p;
+        }
         // ---- timestamp: leading ones of the next four bits select the bucket; payload width
         // 0, 7, 9, 12, 32 and code length 1, 9, 12, 16, 36 sit in 6-bit fields of two constants
         const uint32_t top = (uint32_t)(hi >> 32);
@@ -446,6 +464,13 @@ struct WindowDecoder {
             dd = (int64_t)(int32_t)ext;
         }
         p.dd = ones ? dd : 0;
+        parse_value(p, hi, lo, clen);
+        return p;
+    }
+
+    // The value part of a point whose timestamp code took clen bits.
+    __device__ __forceinline__ void parse_value(Parsed& p, uint64_t hi, uint64_t lo, uint32_t clen) const
+    {
         // ---- value header: the bits after the timestamp code, left-aligned in xh (clen + 14 <= 50)
         const uint32_t xh = (uint32_t)((hi << clen) >> 32);
         const bool c0 = (int32_t)xh < 0;          // '1': the value changed
@@ -472,7 +497,6 @@ struct WindowDecoder {
         p.o1 = off + clen;
         p.o2 = off + p2;
         p.o3 = p.o2 + n;
-        return p;
     }
     __device__ __forceinline__ bool rare(const Parsed& p) const { return p.eos || p.malformed || runs_off(p.o3); }
     __device__ __forceinline__ void commit(const Parsed& p)

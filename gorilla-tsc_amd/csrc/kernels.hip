@@ -607,7 +607,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (!__any(slow_lane)) {                                                               \
             uint64_t hi, lo;                                                                   \
             WindowDecoder<FMT>::window(w0, w1, w2, d.off, hi, lo);                             \
-            const typename WindowDecoder<FMT>::Parsed p = d.parse(hi, lo);                     \
+            /* regular cadence in every live lane: the timestamp code is the bit '0' */        \
+            const typename WindowDecoder<FMT>::Parsed p = __all(!active | ((int64_t)hi >= 0))     \
+                ? d.template parse<true>(hi, lo) : d.template parse<false>(hi, lo);            \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
             /* plain | and &: short-circuit forms would become a chain of branches */          \
