@@ -299,8 +299,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
             const int64_t idx = (int64_t)(((uint64_t)ri_[i].y << 32) | ri_[i].x) + (int64_t)v0; \
             if ((v0 + 1 >= ri_[i].z) & (v0 < ri_[i].w)) {                                      \
-                rt[i] = load16(a.ts + idx);                                                    \
-                rv[i] = load16(a.val + idx);                                                   \
+                /* 16-byte aligned pieces of a stream that is read once */                     \
+                rt[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.ts + idx));   \
+                rv[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx));  \
             }                                                                                  \
         }                                                                                      \
     }
@@ -717,8 +718,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #if GTSC_ABLATE == 4
                 asm volatile("" ::"v"(t), "v"(qv[i]), "v"(idx));
 #else
-                store16(a.ts + idx, t);
-                store16(a.val + idx, qv[i]);
+                // whole aligned lines that nothing reads again soon: streaming stores
+                __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
+                __builtin_nontemporal_store(qv[i], reinterpret_cast<U4*>(a.val + idx));
 #endif
             }
         } else {
