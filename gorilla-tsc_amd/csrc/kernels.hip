@@ -217,14 +217,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
     constexpr uint32_t OFF_VAL = TT::BYTES;
     constexpr uint32_t OFF_RING = OFF_VAL + TILE_BYTES;
     constexpr uint32_t OFF_ROWS = OFF_RING + 64 * RING_ROW_BYTES;
-    constexpr uint32_t OFF_WSTATE = OFF_ROWS + 64 * sizeof(RowInfo);
-    constexpr uint32_t OFF_ZERO = OFF_WSTATE + 64 * 8;
+    constexpr uint32_t OFF_ZERO = OFF_ROWS + 64 * sizeof(RowInfo);
     __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ZERO + 64 * 4 + GTSC_LDS_PAD];
     uint8_t* const tile_ts = lds;
     uint8_t* const tile_val = lds + OFF_VAL;
     uint8_t* const ring = lds + OFF_RING;  // 64 rows x RING_WORDS compressed words
     RowInfo* const rows = reinterpret_cast<RowInfo*>(lds + OFF_ROWS);
-    uint2* const wstate = reinterpret_cast<uint2*>(lds + OFF_WSTATE);  // {flushed, count}
     uint32_t* const rowzero = reinterpret_cast<uint32_t*>(lds + OFF_ZERO);  // v2: bit k = slot k's timestamp is 0
 
     const uint32_t lane = threadIdx.x;
@@ -245,6 +243,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 
     const uint64_t cap64 = valid ? a.slots.size(s) : 0;
     const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
+    const uint64_t sbeg = valid ? a.slots.begin(s) : 0;  // the flusher lanes get it by shuffle
     const int64_t bts = valid ? a.block_ts[s] : 0;
     // Completed words go to the lane's row of the ring (word w in slot w % RING_WORDS); the
     // wavefront copies them out in whole 64-byte blocks.
@@ -257,31 +256,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 
 // Copies ring words [flushed, END) of every row to its slot; END is the row's count rounded
 // down to whole blocks (FINAL == false) or the count itself.  Lane l serves row 8i + l/8,
-// ring slots 2*(l%8) and the next.  Words beyond a row's slot capacity are dropped.
+// ring slots 2*(l%8) and the next.  Words beyond a row's slot capacity are dropped.  What a
+// flusher lane needs to know about a row comes from the row's own lane by shuffle, and all LDS
+// reads are issued before the first store, so the passes do not wait for one another.
 #define GTSC_FLUSH(FINAL)                                                                      \
     {                                                                                          \
-        wstate[lane] = make_uint2(flushed, e.widx);                                            \
-        wave_sync();                                                                       \
-        _Pragma("unroll 1") for (uint32_t i = 0; i < PASSES; i++) {                            \
+        wave_sync(); /* the lanes' ring writes */                                              \
+        uint64_t fx0[PASSES], fx1[PASSES], fdst[PASSES];                                       \
+        uint32_t fmode[PASSES]; /* 0 nothing, 1 first word only, 2 both words */               \
+        _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
             const uint32_t r = lrow + i * ROWS_PER_PASS;                                       \
-            const uint2 ws = wstate[r];                                                        \
-            const uint32_t end = (FINAL) ? ws.y : ws.x + ((ws.y - ws.x) & ~(RING_BLOCK - 1));  \
-            const uint32_t w0 = ws.x + ((2 * piece - ws.x) & (RING_WORDS - 1));                \
-            if (w0 < end && s0 + r < a.nseries) {                                              \
-                const uint64_t* src = reinterpret_cast<const uint64_t*>(ring + r * RING_ROW_BYTES + piece * 16); \
-                const uint64_t x0 = src[0], x1 = src[1];                                       \
-                const uint64_t rcap = a.slots.size(s0 + r);                                    \
-                uint64_t* dst = a.out_words + a.slots.begin(s0 + r) + w0;                      \
-                if (w0 + 1 < end && w0 + 1 < rcap) {                                           \
-                    const U4 v = {(uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32)}; \
-                    store16(dst, v);                                                           \
-                } else if (w0 < rcap) {                                                        \
-                    dst[0] = x0;                                                               \
-                }                                                                              \
+            const uint32_t rf = (uint32_t)__shfl((int)flushed, (int)r, 64);                    \
+            const uint32_t rw = (uint32_t)__shfl((int)e.widx, (int)r, 64);                     \
+            const uint32_t rcap = (uint32_t)__shfl((int)cap, (int)r, 64);                      \
+            const uint32_t end = (FINAL) ? rw : rf + ((rw - rf) & ~(RING_BLOCK - 1));          \
+            const uint32_t w0 = rf + ((2 * piece - rf) & (RING_WORDS - 1));                    \
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(ring + r * RING_ROW_BYTES + piece * 16); \
+            fx0[i] = src[0]; fx1[i] = src[1];                                                  \
+            fdst[i] = shfl_u64(sbeg, r) + w0;                                                  \
+            fmode[i] = (w0 < end && w0 < rcap) ? ((w0 + 1 < end && w0 + 1 < rcap) ? 2u : 1u) : 0u; \
+        }                                                                                      \
+        _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
+            uint64_t* dst = a.out_words + fdst[i];                                             \
+            if (fmode[i] == 2) {                                                               \
+                const U4 v = {(uint32_t)fx0[i], (uint32_t)(fx0[i] >> 32), (uint32_t)fx1[i], (uint32_t)(fx1[i] >> 32)}; \
+                store16(dst, v);                                                               \
+            } else if (fmode[i] == 1) {                                                        \
+                dst[0] = fx0[i];                                                               \
             }                                                                                  \
         }                                                                                      \
         if (!(FINAL)) flushed += (e.widx - flushed) & ~(RING_BLOCK - 1);                       \
-        wave_sync();                                                                       \
+        wave_sync(); /* the slots may be written again */                                      \
     }
 
 // Loads chunk C of the tile into rt/rv (a macro: the arrays must stay in registers).  A piece
