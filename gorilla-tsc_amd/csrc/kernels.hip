@@ -729,31 +729,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #endif
             }
         } else {
+            // ragged chunk (a block's first or last one, or directly stored timestamps): the same
+            // reads up front, then each piece stores what it has
+            uint2 qt[PASSES];
+            U4 qv[PASSES];
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
                 const uint32_t r = lrow + i * ROWS_PER_PASS;
+                qt[i] = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
+                qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < PASSES; i++) {
                 const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
                 const uint32_t rlo = ri[i].z & 255u, rhi = (ri[i].z >> 8) & 255u, direct = ri[i].z >> 16;
                 const bool ok0 = j0 >= rlo && j0 < rhi;
                 const bool ok1 = j0 + 1 >= rlo && j0 + 1 < rhi;
-                if (ok0 || ok1) {
-                    const uint2 tl = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
-                    const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
-                    const bool t0 = ok0 && !((direct >> j0) & 1u), t1 = ok1 && !((direct >> (j0 + 1)) & 1u);
-                    const uint64_t ts0 = ((uint64_t)ri[i].w << 32) | tl.x, ts1 = ((uint64_t)ri[i].w << 32) | tl.y;
-                    if (t0 && t1) {
-                        store16(a.ts + idx, U4{tl.x, ri[i].w, tl.y, ri[i].w});
-                    } else {
-                        if (t0) a.ts[idx] = (int64_t)ts0;
-                        if (t1) a.ts[idx + 1] = (int64_t)ts1;
-                    }
-                    if (ok0 && ok1) {
-                        store16(a.val + idx, v);
-                    } else if (ok0) {
-                        a.val[idx] = lo64(v);
-                    } else {
-                        a.val[idx + 1] = hi64(v);
-                    }
+                const bool t0 = ok0 && !((direct >> j0) & 1u), t1 = ok1 && !((direct >> (j0 + 1)) & 1u);
+                if (ok0 & ok1 & t0 & t1) {
+                    store16(a.ts + idx, U4{qt[i].x, ri[i].w, qt[i].y, ri[i].w});
+                    store16(a.val + idx, qv[i]);
+                } else if (ok0 | ok1) {
+                    if (t0) a.ts[idx] = (int64_t)(((uint64_t)ri[i].w << 32) | qt[i].x);
+                    if (t1) a.ts[idx + 1] = (int64_t)(((uint64_t)ri[i].w << 32) | qt[i].y);
+                    if (ok0) a.val[idx] = lo64(qv[i]);
+                    if (ok1) a.val[idx + 1] = hi64(qv[i]);
                 }
             }
         }
