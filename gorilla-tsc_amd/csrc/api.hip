@@ -230,7 +230,7 @@ int gtsc_encode_device_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t ns
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
-                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, tables, c->dfcm_mask};
+                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, tables, c->dfcm_mask, 0u};
     HIP_TRY(launch_encode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -288,7 +288,7 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
-                 out_npoints, status, c->d_flags, tables, c->dfcm_mask};
+                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -466,7 +466,7 @@ int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* b
         }
         EncodeArgs a{ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
                      Layout{d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot},
-                     st.nwords.as<uint64_t>(), nullptr, c->d_flags, nullptr, 0u, nullptr, c->dfcm_mask};
+                     st.nwords.as<uint64_t>(), nullptr, c->d_flags, nullptr, 0u, nullptr, c->dfcm_mask, 0u};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_encode(a, format, st.stream));
         uint64_t* scratch = c->scan_scratch.as<uint64_t>() + (size_t)b * scan_scratch_words(CHUNK_SERIES);
@@ -531,7 +531,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, st.stream));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
-                     st.status.as<uint32_t>(), c->d_flags, nullptr, c->dfcm_mask};
+                     st.status.as<uint32_t>(), c->d_flags, nullptr, c->dfcm_mask, 0u};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, st.stream));
         if (np) {

@@ -161,6 +161,33 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t x, uint32_t src_lane)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Which series a lane of a tiled kernel codes.  With a uniform number of points per series the
+// position of a series inside its 128-byte lines (its phase) repeats every T = 2^shift series;
+// a wave then takes every T-th series, so that all its rows share one phase and start and end
+// their chunks together (T consecutive workgroups cover 64*T consecutive series).  shift = 0:
+// consecutive series.
+__device__ __forceinline__ uint64_t series_of_lane(uint32_t block, uint32_t lane, uint32_t shift)
+{
+    const uint64_t T = 1ull << shift;
+    return ((uint64_t)(block >> shift) << (6 + shift)) + (block & (T - 1)) + ((uint64_t)lane << shift);
+}
+// shift for a layout: uniform point counts only; phase period = 16 / gcd(points mod 16, 16) series
+static uint32_t group_shift_of(const Layout& pts)
+{
+#ifdef GTSC_STAMP
+    return 0;  // the stamps of a wave overwrite the outputs of the series after its first
+#endif
+    if (pts.off) return 0;
+    const uint32_t m = (uint32_t)(pts.uniform & 15);
+    if (m == 0) return 0;
+    return 4u - (uint32_t)__builtin_ctz(m);  // m = 8 -> 1, 4 or 12 -> 2, even -> 3, odd -> 4
+}
+static uint32_t grouped_blocks(uint64_t nseries, uint32_t shift)
+{
+    const uint64_t per = 64ull << shift;
+    return (uint32_t)(((nseries + per - 1) / per) << shift);
+}
+
 // what a loader lane needs to know about a row
 struct alignas(16) RowInfo {
     int64_t base;  // array index of virtual slot 0 (first point index - phi)
@@ -226,8 +253,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
     uint32_t* const rowzero = reinterpret_cast<uint32_t*>(lds + OFF_ZERO);  // v2: bit k = slot k's timestamp is 0
 
     const uint32_t lane = threadIdx.x;
-    const uint64_t s0 = (uint64_t)blockIdx.x * 64;
-    const uint64_t s = s0 + lane;
+    const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
     const bool valid = s < a.nseries;
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t np64 = valid ? a.pts.size(s) : 0;
@@ -475,8 +501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint64_t tk_p1 = 0, tk_p2 = 0;
 #endif
     const uint32_t lane = threadIdx.x;
-    const uint64_t s0 = (uint64_t)blockIdx.x * 64;
-    const uint64_t s = s0 + lane;
+    const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
     const bool valid = s < a.nseries;
 #ifdef GTSC_STAMP
     uint64_t tk_pk;
@@ -962,9 +987,11 @@ hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
     } else {
-        const uint32_t blocks = (uint32_t)((a.nseries + 63) / 64);
-        if (format == FMT_V2) hipLaunchKernelGGL(encode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, a);
-        else                  hipLaunchKernelGGL(encode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, a);
+        EncodeArgs g = a;
+        g.group_shift = group_shift_of(a.pts);
+        const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
+        if (format == FMT_V2) hipLaunchKernelGGL(encode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, g);
+        else                  hipLaunchKernelGGL(encode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, g);
     }
     return hipGetLastError();
 }
@@ -981,9 +1008,11 @@ hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream)
         if (format == FMT_V2) hipLaunchKernelGGL(decode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(decode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
     } else {
-        const uint32_t blocks = (uint32_t)((a.nseries + 63) / 64);
-        if (format == FMT_V2) hipLaunchKernelGGL(decode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, a);
-        else                  hipLaunchKernelGGL(decode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, a);
+        DecodeArgs g = a;
+        g.group_shift = group_shift_of(a.pts);
+        const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
+        if (format == FMT_V2) hipLaunchKernelGGL(decode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, g);
+        else                  hipLaunchKernelGGL(decode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, g);
     }
     return hipGetLastError();
 }

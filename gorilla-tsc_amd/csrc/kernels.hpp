@@ -23,6 +23,7 @@ struct EncodeArgs {
     uint32_t no_close;   // nonzero: leave the blocks open (image = snapshot of getLongArray())
     int64_t* dfcm_tables;  // DFCM predictor: nseries zero-filled tables of dfcm_mask + 1 entries; null = last-value predictor
     uint32_t dfcm_mask;
+    uint32_t group_shift;  // set by the launcher (tiled kernels): see series_of_lane()
 };
 
 struct DecodeArgs {
@@ -38,6 +39,7 @@ struct DecodeArgs {
     uint32_t* flags;
     int64_t* dfcm_tables;     // as in EncodeArgs
     uint32_t dfcm_mask;
+    uint32_t group_shift;     // as in EncodeArgs
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);
