@@ -197,6 +197,24 @@ def test_uniform_and_csr_layouts_agree(ctx):
         assert np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("P,S", [(1, 70), (7, 1), (7, 300), (100, 65), (121, 1030), (123, 2500), (136, 129), (200, 64)])
+def test_uniform_layouts_of_any_length(ctx, P, S):
+    """Uniform layouts whose series start at every phase of a 128-byte line (the waves then take
+    every 2nd, 4th, 8th or 16th series) and whose count is not a multiple of a wave's share."""
+    b = synth.gauge_drift(S=S, P=P, seed=1000 + P)
+    for gfmt, ofmt in FMTS:
+        out, off, nw, st, rc, d_out, d_nw = gpu_encode(ctx, b, gfmt, uniform=True)
+        assert rc == 0 and not st.any()
+        ref_out, ref_off, ref_nw, _ = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, out_off=off, fmt=ofmt, nthreads=4)
+        assert np.array_equal(nw, ref_nw)
+        for s in range(S):
+            a0, n = int(off[s]), int(nw[s])
+            assert np.array_equal(out[a0:a0 + n], ref_out[a0:a0 + n]), (P, S, s)
+        ts, val, npts, st2, rc2 = gpu_decode(ctx, out, off, nw, b.pt_off, gfmt, uniform_cap=P, d_words=d_out)
+        assert rc2 == 0 and not st2.any() and np.all(npts == P)
+        assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+
+
 def test_compaction(ctx):
     b = synth.ragged_mix(seed=11, nseries=3000, pmax=150)
     out, off, nw, d_out, d_nw = check_encode_against_oracle(ctx, b, G.FMT_V2, O.V2)
