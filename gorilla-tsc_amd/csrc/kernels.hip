@@ -198,10 +198,14 @@ struct alignas(16) RowInfo {
 constexpr uint32_t MAX_ROW_POINTS = 0x7FFFFF00u;
 
 // Output ring of the encoder: per row RING_WORDS words, copied out in blocks of RING_BLOCK.
-// Between two flush checks (4 points) a row gains at most 4 * 114 bits = 7.2 words on top
-// of at most RING_BLOCK - 1 words that were not yet a whole block.
+// The rows are looked at after every two points, and a copy is made when some row holds
+// RING_TRIGGER or more words that are not yet written out: two points add at most 228 bits,
+// which moves the word being filled at most 4 slots on, so below the trigger a row stays
+// within its 16 slots until the next look.  Copying as late as that lets many rows have a
+// whole block by the time one row forces the copy.
 constexpr uint32_t RING_WORDS = 16;
 constexpr uint32_t RING_BLOCK = 8;
+constexpr uint32_t RING_TRIGGER = RING_WORDS - 4;
 
 #ifndef GTSC_LDS_PAD
 #define GTSC_LDS_PAD 0
@@ -390,10 +394,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #else
                     e.add_next(tl.x, 0u, lo64(va), sink);
                     e.add_next(tl.y, 0u, hi64(va), sink);
+                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                     e.add_next(tl.z, 0u, lo64(vb), sink);
                     e.add_next(tl.w, 0u, hi64(vb), sink);
 #endif
-                    if (__any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                 }
             } else {
 #pragma unroll 1
@@ -405,9 +410,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     const uint32_t zq = zbits >> (2 * q);
                     if (k < np) e.add_lo(bts_lo, tl.x, zq & 1u, lo64(va), sink);
                     if (k + 1 < np) e.add_lo(bts_lo, tl.y, (zq >> 1) & 1u, hi64(va), sink);
+                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                     if (k + 2 < np) e.add_lo(bts_lo, tl.z, (zq >> 2) & 1u, lo64(vb), sink);
                     if (k + 3 < np) e.add_lo(bts_lo, tl.w, (zq >> 3) & 1u, hi64(vb), sink);
-                    if (__any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                 }
             }
         } else {
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 const uint32_t k = c * CH + 2 * q - phi;
                 if (k < np) e.add(bts, (int64_t)lo64(t), lo64(v), sink);
                 if (k + 1 < np) e.add(bts, (int64_t)hi64(t), hi64(v), sink);
-                if ((q & 1) && __any(e.widx - flushed >= RING_BLOCK)) GTSC_FLUSH(false)
+                if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
             }
         }
         GTSC_TICK(tk_comp)

@@ -9,8 +9,9 @@ import numpy as np, torch
 import pygtsc as G
 import bench
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-S = 1_000_000
-block, ts, val = bench.make_workload("gauge", S, P, torch.device("cuda"), 1)
+WORKLOAD = sys.argv[2] if len(sys.argv) > 2 else "gauge"
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+block, ts, val = bench.make_workload(WORKLOAD, S, P, torch.device("cuda"), 1)
 slot = G.max_words(P)
 out = torch.zeros(S * slot, dtype=torch.int64, device="cuda")
 nw = torch.zeros(S, dtype=torch.int64, device="cuda")
