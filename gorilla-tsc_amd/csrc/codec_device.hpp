@@ -431,8 +431,10 @@ struct WindowDecoder {
     // Branch-free parse of an ordinary point from 128 bits of stream (hi,lo) at the current position.
     // TS_ZERO: the caller has seen that the timestamp code is the single bit '0' (regular
     // cadence, the common case by far), so that part folds away.
-    template <bool TS_ZERO = false>
-    __device__ __forceinline__ Parsed parse(uint64_t hi, uint64_t lo) const
+    // `lo` is a callable giving the second 64 bits of the window: it is only called when some
+    // lane's payload reaches past the first 64 (never, for well compressible data).
+    template <bool TS_ZERO = false, class Lo>
+    __device__ __forceinline__ Parsed parse(uint64_t hi, Lo lo) const
     {
         Parsed p;
         if (TS_ZERO) {
@@ -469,7 +471,8 @@ struct WindowDecoder {
     }
 
     // The value part of a point whose timestamp code took clen bits.
-    __device__ __forceinline__ void parse_value(Parsed& p, uint64_t hi, uint64_t lo, uint32_t clen) const
+    template <class Lo>
+    __device__ __forceinline__ void parse_value(Parsed& p, uint64_t hi, Lo lo, uint32_t clen) const
     {
         // ---- value header: the bits after the timestamp code, left-aligned in xh (clen + 14 <= 50)
         const uint32_t xh = (uint32_t)((hi << clen) >> 32);
@@ -492,7 +495,8 @@ struct WindowDecoder {
         const uint32_t p2 = clen + hlen;  // <= 50: start of the payload inside (hi,lo)
         p.malformed = c0 & (p.nbits == 0);
         const uint32_t n = c0 ? p.nbits : 0u;  // 1..64 once a window exists
-        const uint64_t pay = (hi << p2) | ((lo >> 1) >> (63 - p2));
+        uint64_t pay = hi << p2;
+        if (__any(p2 + n > 64)) pay |= (lo() >> 1) >> (63 - p2);  // wave-uniform: the second half of the window is needed
         p.bits = n ? (pay >> ((64u - n) & 63u)) : 0ull;
         p.o1 = off + clen;
         p.o2 = off + p2;
@@ -508,10 +512,10 @@ struct WindowDecoder {
         stored_ts += (uint64_t)stored_delta;
         advance(p.o3);
     }
-    __device__ __forceinline__ static void window(uint64_t w0, uint64_t w1, uint64_t w2, uint32_t off, uint64_t& hi, uint64_t& lo)
+    // 64 bits of stream starting `off` bits into word a (b is the word after it)
+    __device__ __forceinline__ static uint64_t window(uint64_t a, uint64_t b, uint32_t off)
     {
-        hi = (w0 << off) | ((w1 >> 1) >> (63 - off));
-        lo = (w1 << off) | ((w2 >> 1) >> (63 - off));
+        return (a << off) | ((b >> 1) >> (63 - off));
     }
 
     // Decodes the next pair from the window (w0,w1,w2 = words widx..widx+2).
@@ -519,8 +523,7 @@ struct WindowDecoder {
     __device__ __forceinline__ bool next(uint64_t w0, uint64_t w1, uint64_t w2, int64_t& ts_out, uint64_t& val_out)
     {
         if (st) return false;
-        uint64_t hi, lo;
-        window(w0, w1, w2, off, hi, lo);
+        const uint64_t hi = window(w0, w1, off), lo = window(w1, w2, off);
         if (__builtin_expect(stored_ts == 0, 0)) {
             // first(): 27-bit delta, 64-bit value
             const uint32_t d = (uint32_t)(hi >> 37);
@@ -534,7 +537,7 @@ struct WindowDecoder {
             ts_out = (int64_t)stored_ts; val_out = val;
             return true;
         }
-        const Parsed p = parse(hi, lo);
+        const Parsed p = parse(hi, [lo] { return lo; });
         if (__builtin_expect(rare(p), 0)) {
             // rare outcomes, in the order the reference's reads meet them
             if (runs_off(p.o1)) st |= ST_TRUNCATED;

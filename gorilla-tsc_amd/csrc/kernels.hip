@@ -642,8 +642,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         GTSC_WINDOW_READ()                                                                     \
         bool done = false;                                                                     \
         if (!__any(slow_lane)) {                                                               \
-            uint64_t hi, lo;                                                                   \
-            WindowDecoder<FMT>::window(w0, w1, w2, d.off, hi, lo);                             \
+            const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);                     \
+            const uint32_t off0 = d.off;                                                       \
+            auto lo = [w1, w2, off0] { return WindowDecoder<FMT>::window(w1, w2, off0); };     \
             /* regular cadence in every live lane: the timestamp code is the bit '0' */        \
             const typename WindowDecoder<FMT>::Parsed p = __all(!active | ((int64_t)hi >= 0))     \
                 ? d.template parse<true>(hi, lo) : d.template parse<false>(hi, lo);            \
