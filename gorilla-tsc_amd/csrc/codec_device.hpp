@@ -34,6 +34,11 @@ struct Layout {
     __device__ __forceinline__ uint64_t size(uint64_t s) const { return off ? off[s + 1] - off[s] : uniform; }
 };
 
+// Wave votes straight on the condition's lane mask (the library forms go through an integer
+// per lane: two more instructions each, in loops where a dozen of them run per point).
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+__device__ __forceinline__ bool all_lanes(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
+
 __device__ __forceinline__ uint32_t clz64(uint64_t x) { return (uint32_t)__builtin_clzll(x); }  // x != 0
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }  // x != 0
 
@@ -149,7 +154,7 @@ struct Encoder {
             // int arithmetic: only the low 32 bits of the timestamps take part
             const uint32_t nd = ts_lo - pts_lo;
             const int32_t dod = (int32_t)(nd - (uint32_t)(int32_t)stored_delta);
-            if (__all(dod == 0)) {
+            if (all_lanes(dod == 0)) {
                 // regular cadence in every lane (the common case by far): the code is the single bit '0'
                 tlen = 1u; tlo = 0u; thi = 0u;
             } else {
@@ -173,7 +178,7 @@ struct Encoder {
             const uint64_t ts = ((uint64_t)ts_hi << 32) | ts_lo, pts = ((uint64_t)pts_hi << 32) | pts_lo;
             const uint64_t nd = ts - pts;
             const uint64_t dod = nd - (uint64_t)stored_delta;
-            if (__all(dod == 0)) {
+            if (all_lanes(dod == 0)) {
                 tlen = 1u; tlo = 0u; thi = 0u;  // regular cadence in every lane
             } else {
                 const bool zero = dod == 0;
@@ -496,7 +501,7 @@ struct WindowDecoder {
         p.malformed = c0 & (p.nbits == 0);
         const uint32_t n = c0 ? p.nbits : 0u;  // 1..64 once a window exists
         uint64_t pay = hi << p2;
-        if (__any(p2 + n > 64)) pay |= (lo() >> 1) >> (63 - p2);  // wave-uniform: the second half of the window is needed
+        if (any_lane(p2 + n > 64)) pay |= (lo() >> 1) >> (63 - p2);  // wave-uniform: the second half of the window is needed
         p.bits = n ? (pay >> ((64u - n) & 63u)) : 0ull;
         p.o1 = off + clen;
         p.o2 = off + p2;

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
             const uint32_t bts_lo = (uint32_t)bts;
             // every lane has all 16 slots occupied, is past its first point and sees no zero
             // timestamp: no guards, no first-point test, four points per step
-            if (__all(interior && e.started && zbits == 0)) {
+            if (all_lanes(interior && e.started && zbits == 0)) {
 #pragma unroll 1
                 for (uint32_t q = 0; q < PIECES; q += 2) {
                     const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
@@ -394,11 +394,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #else
                     e.add_next(tl.x, 0u, lo64(va), sink);
                     e.add_next(tl.y, 0u, hi64(va), sink);
-                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                     e.add_next(tl.z, 0u, lo64(vb), sink);
                     e.add_next(tl.w, 0u, hi64(vb), sink);
 #endif
-                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                 }
             } else {
 #pragma unroll 1
@@ -410,10 +410,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     const uint32_t zq = zbits >> (2 * q);
                     if (k < np) e.add_lo(bts_lo, tl.x, zq & 1u, lo64(va), sink);
                     if (k + 1 < np) e.add_lo(bts_lo, tl.y, (zq >> 1) & 1u, hi64(va), sink);
-                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                     if (k + 2 < np) e.add_lo(bts_lo, tl.z, (zq >> 2) & 1u, lo64(vb), sink);
                     if (k + 3 < np) e.add_lo(bts_lo, tl.w, (zq >> 3) & 1u, hi64(vb), sink);
-                    if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                 }
             }
         } else {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 const uint32_t k = c * CH + 2 * q - phi;
                 if (k < np) e.add(bts, (int64_t)lo64(t), lo64(v), sink);
                 if (k + 1 < np) e.add(bts, (int64_t)hi64(t), hi64(v), sink);
-                if (__any(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
             }
         }
         GTSC_TICK(tk_comp)
@@ -641,19 +641,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     {                                                                                          \
         GTSC_WINDOW_READ()                                                                     \
         bool done = false;                                                                     \
-        if (!__any(slow_lane)) {                                                               \
+        if (!any_lane(slow_lane)) {                                                               \
             const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);                     \
             const uint32_t off0 = d.off;                                                       \
             auto lo = [w1, w2, off0] { return WindowDecoder<FMT>::window(w1, w2, off0); };     \
             /* regular cadence in every live lane: the timestamp code is the bit '0' */        \
-            const typename WindowDecoder<FMT>::Parsed p = __all(!active | ((int64_t)hi >= 0))     \
+            const typename WindowDecoder<FMT>::Parsed p = all_lanes(!active | ((int64_t)hi >= 0))     \
                 ? d.template parse<true>(hi, lo) : d.template parse<false>(hi, lo);            \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
             /* plain | and &: short-circuit forms would become a chain of branches */          \
             const bool rare = active & (p.eos | p.malformed | (t.widx >= guard) | (t.stored_ts == 0) | \
                                         ((uint32_t)(t.stored_ts >> 32) != ts_ref));            \
-            if (GTSC_FORCE_FAST || !__any(rare)) {                                             \
+            if (GTSC_FORCE_FAST || !any_lane(rare)) {                                             \
                 d = t;                                                                         \
                 GTSC_TILE_WRITE(uint32_t, tile_ts + adt + (KK) * 4, d.stored_ts)               \
                 GTSC_TILE_WRITE(uint64_t, tile_val + ad + (KK) * 8, d.val)                     \
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             /* a lane that has run ahead of its top-ups waits for the words of its next window */ \
             for (;;) {                                                                         \
                 const bool shortw = active && filled < nw && d.widx + 2 >= filled;             \
-                if (!__any(shortw)) break;                                                     \
+                if (!any_lane(shortw)) break;                                                     \
                 dense = 3;                                                                     \
                 if (shortw) {                                                                  \
                     if (!pend) GTSC_TOPUP_ISSUE()                                              \
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             slow_lane = active && (skip != 0 || d.stored_ts == 0);                             \
         }                                                                                      \
     }
-    for (uint32_t c = 0; __any(active); c++) {
+    for (uint32_t c = 0; any_lane(active); c++) {
         ts_ref = (uint32_t)(d.stored_ts >> 32);
         n0 = n;
         dmask = 0;
@@ -711,14 +711,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const uint32_t adt = dec_ts_addr(lane, 2 * k2);
             GTSC_POINT(0)
             if (dense) {  // a stream this dense needs a top-up per point to keep up (2 words per point at most)
-                if (__any(pend)) { if (pend) GTSC_TOPUP_LAND() }
+                if (any_lane(pend)) { if (pend) GTSC_TOPUP_LAND() }
                 const bool low0 = d.widx >= limit;
-                if (__any(low0)) { if (low0) GTSC_TOPUP_ISSUE() }
+                if (any_lane(low0)) { if (low0) GTSC_TOPUP_ISSUE() }
             }
             GTSC_POINT(1)
-            if (__any(pend)) { if (pend) GTSC_TOPUP_LAND() }
+            if (any_lane(pend)) { if (pend) GTSC_TOPUP_LAND() }
             const bool low = d.widx >= limit;
-            if (__any(low)) { if (low) GTSC_TOPUP_ISSUE() }
+            if (any_lane(low)) { if (low) GTSC_TOPUP_ISSUE() }
         }
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
         if (active && c * DCH >= cap) { active = false; nfin = n; }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         U4 ri[PASSES];
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
-        if (__all(info == DEC_ROW_FULL)) {
+        if (all_lanes(info == DEC_ROW_FULL)) {
             // every row has all 16 slots of this chunk: read everything, then store everything
             uint2 qt[PASSES];
             U4 qv[PASSES];
