@@ -36,6 +36,10 @@ struct Layout {
 
 // Wave votes straight on the condition's lane mask (the library forms go through an integer
 // per lane: two more instructions each, in loops where a dozen of them run per point).
+// lanes(p): the mask of lanes where p holds.  Given a comparison it is that comparison's own
+// result; given a stored or combined flag the compiler rebuilds it through a register, so the
+// hot loops keep flags as integers, vote on comparisons and combine the masks.
+__device__ __forceinline__ uint64_t lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 __device__ __forceinline__ bool all_lanes(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
 
@@ -431,6 +435,7 @@ struct WindowDecoder {
         uint64_t bits;        // payload, right-aligned
         int64_t dd;           // delta of delta
         bool eos, malformed;
+        bool changed;         // the value code starts with '1' (malformed = changed and no window yet)
     };
 
     // Branch-free parse of an ordinary point from 128 bits of stream (hi,lo) at the current position.
@@ -499,6 +504,7 @@ struct WindowDecoder {
         hlen = c0 ? (fresh ? hlen : 2u) : 1u;
         const uint32_t p2 = clen + hlen;  // <= 50: start of the payload inside (hi,lo)
         p.malformed = c0 & (p.nbits == 0);
+        p.changed = c0;
         const uint32_t n = c0 ? p.nbits : 0u;  // 1..64 once a window exists
         uint64_t pay = hi << p2;
         if (any_lane(p2 + n > 64)) pay |= (lo() >> 1) >> (63 - p2);  // wave-uniform: the second half of the window is needed

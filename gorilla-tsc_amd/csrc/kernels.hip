@@ -608,7 +608,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t nfin = 0;
     uint32_t st = 0;
     uint32_t skip = phi;               // slots of the first chunk that lie before the row's first point
-    bool slow_lane = valid;            // this lane's next point needs the serial path (first point, zero timestamp, skip)
+    uint32_t slow_w = valid ? 1u : 0u; // 1: this lane's next point needs the serial path (first point, zero timestamp, skip)
+    uint64_t active_m = lanes(valid);  // wave-uniform: the lanes still decoding
     uint32_t ts_ref = 0;               // high half that this chunk's timestamps of the lane share
     uint32_t n0 = 0;                   // n when the chunk began
     uint32_t dmask = 0;                // slots of this chunk whose timestamps the lane stored itself
@@ -641,19 +642,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     {                                                                                          \
         GTSC_WINDOW_READ()                                                                     \
         bool done = false;                                                                     \
-        if (!any_lane(slow_lane)) {                                                               \
+        if (lanes(slow_w != 0) == 0) {                                                         \
             const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);                     \
             const uint32_t off0 = d.off;                                                       \
             auto lo = [w1, w2, off0] { return WindowDecoder<FMT>::window(w1, w2, off0); };     \
             /* regular cadence in every live lane: the timestamp code is the bit '0' */        \
-            const typename WindowDecoder<FMT>::Parsed p = all_lanes(!active | ((int64_t)hi >= 0))     \
+            const typename WindowDecoder<FMT>::Parsed p = (lanes((int64_t)hi < 0) & active_m) == 0 \
                 ? d.template parse<true>(hi, lo) : d.template parse<false>(hi, lo);            \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
-            /* plain | and &: short-circuit forms would become a chain of branches */          \
-            const bool rare = active & (p.eos | p.malformed | (t.widx >= guard) | (t.stored_ts == 0) | \
-                                        ((uint32_t)(t.stored_ts >> 32) != ts_ref));            \
-            if (GTSC_FORCE_FAST || !any_lane(rare)) {                                             \
+            /* each vote is one comparison; the masks are combined as scalars */               \
+            const uint64_t rare_m = (lanes(p.eos) | (lanes(p.changed) & lanes(p.nbits == 0)) | \
+                                     lanes(t.widx >= guard) | lanes(t.stored_ts == 0) |        \
+                                     lanes((uint32_t)(t.stored_ts >> 32) != ts_ref)) & active_m; \
+            if (GTSC_FORCE_FAST || rare_m == 0) {                                              \
                 d = t;                                                                         \
                 GTSC_TILE_WRITE(uint32_t, tile_ts + adt + (KK) * 4, d.stored_ts)               \
                 GTSC_TILE_WRITE(uint64_t, tile_val + ad + (KK) * 8, d.val)                     \
@@ -697,7 +699,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     GTSC_TOPUP_LAND()                                                          \
                 }                                                                              \
             }                                                                                  \
-            slow_lane = active && (skip != 0 || d.stored_ts == 0);                             \
+            slow_w = (active && (skip != 0 || d.stored_ts == 0)) ? 1u : 0u;                    \
+            active_m = lanes(active);                                                          \
         }                                                                                      \
     }
     for (uint32_t c = 0; any_lane(active); c++) {
