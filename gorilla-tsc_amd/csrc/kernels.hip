@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     if (valid) d.begin(nw, my_ring[0]);
 
     // ---- top-up state: the lane's load in flight between two checks
-    bool pend = false;
+    uint32_t pend = 0;  // 1: a top-up of this lane is in flight (an integer: see lanes())
     uint32_t dense = 0;  // wave-uniform: > 0 after a lane outran its top-ups: the rings are then looked after at every point for a while
     U4 tq;  // defined whenever pend is set
     uint32_t tback = 0;
@@ -595,12 +595,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         filled += 2;                                                                           \
         guard = filled >= nw ? nw : filled - 2;                                                \
         limit = (filled >= nw || !active) ? IN_NEVER : filled - IN_RING_LOW;                   \
-        pend = false;                                                                          \
+        pend = 0;                                                                              \
     }
 #define GTSC_TOPUP_ISSUE()                                                                     \
     {                                                                                          \
         GTSC_RING_LOAD(tq, tback, filled)                                                      \
-        pend = true;                                                                           \
+        pend = 1;                                                                              \
         limit = IN_NEVER; /* nothing more until this one has landed */                         \
     }
 
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             active_m = lanes(active);                                                          \
         }                                                                                      \
     }
-    for (uint32_t c = 0; any_lane(active); c++) {
+    for (uint32_t c = 0; active_m != 0; c++) {
         ts_ref = (uint32_t)(d.stored_ts >> 32);
         n0 = n;
         dmask = 0;
@@ -714,17 +714,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const uint32_t adt = dec_ts_addr(lane, 2 * k2);
             GTSC_POINT(0)
             if (dense) {  // a stream this dense needs a top-up per point to keep up (2 words per point at most)
-                if (any_lane(pend)) { if (pend) GTSC_TOPUP_LAND() }
+                if (lanes(pend != 0)) { if (pend) GTSC_TOPUP_LAND() }
                 const bool low0 = d.widx >= limit;
                 if (any_lane(low0)) { if (low0) GTSC_TOPUP_ISSUE() }
             }
             GTSC_POINT(1)
-            if (any_lane(pend)) { if (pend) GTSC_TOPUP_LAND() }
+            if (lanes(pend != 0)) { if (pend) GTSC_TOPUP_LAND() }
             const bool low = d.widx >= limit;
             if (any_lane(low)) { if (low) GTSC_TOPUP_ISSUE() }
         }
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
         if (active && c * DCH >= cap) { active = false; nfin = n; }
+        active_m = lanes(active);
 #endif
         GTSC_TICK(tk_comp)
         // ---- flush the chunk: what this row has to write out, in slots of this chunk
