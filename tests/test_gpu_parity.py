@@ -282,6 +282,60 @@ def test_decode_capacity_overflow_and_bad_streams(ctx):
     assert rc == G.ERR_STREAM and st[0] == rst[0] == G.ST_MALFORMED and npts[0] == rnp[0] == 1
 
 
+def check_decode_against_oracle(ctx, words, off, nw, cap_off, gfmt, ofmt, uniform_cap=None):
+    ts, val, npts, st, rc = gpu_decode(ctx, words, off, nw, cap_off, gfmt, uniform_cap=uniform_cap)
+    rts, rval, rnp, rst = O.decode_batch(words, off, nw, cap_off, fmt=ofmt)
+    assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+    assert (rc != 0) == bool(rst.any())
+    for s in range(len(off) - 1):
+        a0, a1 = int(cap_off[s]), int(cap_off[s + 1])
+        n = min(int(npts[s]), a1 - a0)
+        assert np.array_equal(ts[a0:a0 + n], rts[a0:a0 + n]) and np.array_equal(val[a0:a0 + n], rval[a0:a0 + n]), s
+        assert np.all(ts[a0 + n:a1] == -7) and np.all(val[a0 + n:a1] == np.uint64(-7 & (2 ** 64 - 1))), s  # fill pattern untouched
+    return st
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_garbage_images_decode_like_the_oracle(ctx, gfmt, ofmt, seed):
+    """Images that no compressor wrote -- random words, runs of zeros and ones, any declared
+    length -- must give the oracle's counts, status words and points, and leave every byte beyond
+    a row's points alone (uniform and per-series layouts, capacity smaller than many streams)."""
+    rng = np.random.default_rng(seed)
+    S, W, CAP = 3000, 24, 96
+    words = rng.integers(0, 2 ** 63, S * W, dtype=np.int64).view(np.uint64) * np.uint64(2) + rng.integers(0, 2, S * W).astype(np.uint64)
+    words[rng.random(S * W) < 0.3] = 0
+    words[rng.random(S * W) < 0.1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    off = np.arange(S + 1, dtype=np.uint64) * np.uint64(W)
+    nw = rng.integers(0, W + 1, S).astype(np.uint64)
+    cap_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(CAP)
+    st = check_decode_against_oracle(ctx, words, off, nw, cap_off, gfmt, ofmt, uniform_cap=CAP)
+    assert len(np.unique(st)) >= 4  # the case mix really covers the status words
+    # per-series layout: ragged slots and capacities
+    lens = rng.integers(0, 40, S)
+    roff = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum(lens, out=roff[1:])
+    rwords = words[: int(roff[-1])] if int(roff[-1]) <= len(words) else np.resize(words, int(roff[-1]))
+    caps = rng.integers(0, 150, S)
+    rcap = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum(caps, out=rcap[1:])
+    check_decode_against_oracle(ctx, rwords, roff, None, rcap, gfmt, ofmt)
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_damaged_images_decode_like_the_oracle(ctx, gfmt, ofmt):
+    """Valid images with a few bits flipped: whatever the damage turns the stream into, the GPU
+    decoder and the oracle read the same points out of it."""
+    rng = np.random.default_rng(77)
+    b = synth.ragged_mix(seed=8, nseries=1500, pmax=200)
+    out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt)
+    bad = out.copy()
+    total = int(off[-1])
+    hits = rng.integers(0, total, total // 40)
+    bad[hits] ^= np.uint64(1) << rng.integers(0, 64, len(hits)).astype(np.uint64)
+    check_decode_against_oracle(ctx, bad, off, nw, b.pt_off, gfmt, ofmt)
+
+
 @pytest.mark.parametrize("gfmt,ofmt", FMTS)
 def test_quirks_first_ts_zero_and_int_wrap(ctx, gfmt, ofmt):
     B = 1500400800000
