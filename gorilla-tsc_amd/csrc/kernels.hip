@@ -589,6 +589,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t dense = 0;  // wave-uniform: > 0 after a lane outran its top-ups: the rings are then looked after at every point for a while
     U4 tq;  // defined whenever pend is set
     uint32_t tback = 0;
+    // The source of the next top-up is worked out when the ring's end moves, not when the load is
+    // made: computed on the spot, the address would go through registers that the compiler takes
+    // from the previous top-up's, and writing those makes it wait for everything in flight --
+    // the chunk's stores included (one counter, in order).
+    const uint64_t* tsrc = image;
+#define GTSC_TOPUP_NEXT()                                                                      \
+    {                                                                                          \
+        tback = (filled + 1 < ssz) ? 0u : 1u;                                                  \
+        tsrc = image + (filled - tback);                                                       \
+    }
+    GTSC_TOPUP_NEXT()
 #define GTSC_TOPUP_LAND()                                                                      \
     {                                                                                          \
         GTSC_RING_STORE(tq, tback, filled)                                                     \
@@ -596,10 +607,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         guard = filled >= nw ? nw : filled - 2;                                                \
         limit = (filled >= nw || !active) ? IN_NEVER : filled - IN_RING_LOW;                   \
         pend = 0;                                                                              \
+        GTSC_TOPUP_NEXT()                                                                      \
     }
-#define GTSC_TOPUP_ISSUE()                                                                     \
+#define GTSC_TOPUP_ISSUE() /* lanes with widx >= limit: filled < nw <= ssz */                  \
     {                                                                                          \
-        GTSC_RING_LOAD(tq, tback, filled)                                                      \
+        tq = load16(tsrc);                                                                     \
         pend = 1;                                                                              \
         limit = IN_NEVER; /* nothing more until this one has landed */                         \
     }
@@ -798,6 +810,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     }
 #undef GTSC_TOPUP_LAND
 #undef GTSC_TOPUP_ISSUE
+#undef GTSC_TOPUP_NEXT
 #undef GTSC_RING_LOAD
 #undef GTSC_RING_STORE
 #undef GTSC_POINT
