@@ -15,7 +15,8 @@
 // Measurement switches, never set in the shipped library:
 //   -DGTSC_STAMP        per-wave cycle stamps (s_memtime) left in the outputs, read by tools/stamps.py
 //   -DGTSC_ABLATE=n     leaves one cost out to see what it is worth (1/3: encoder arithmetic, 4: decoder
-//                       stores, 5: decoder tile writes, 6: decoder ring reads, 7: both); results are wrong
+//                       stores, 5: decoder tile writes, 6: decoder ring reads, 7: both, 8: the encoder's stores
+//                       of compressed words before the last copy); results are wrong
 //   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy
 #ifndef GTSC_ABLATE
 #define GTSC_ABLATE 0
@@ -308,7 +309,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         }                                                                                      \
         _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
             uint64_t* dst = a.out_words + fdst[i];                                             \
-            if (fmode[i] == 2) {                                                               \
+            if (GTSC_ABLATE == 8 && !(FINAL)) {                                                \
+                asm volatile("" ::"v"(fx0[i]), "v"(fx1[i]), "v"(dst), "v"(fmode[i]));          \
+            } else if (fmode[i] == 2) {                                                        \
                 const U4 v = {(uint32_t)fx0[i], (uint32_t)(fx0[i] >> 32), (uint32_t)fx1[i], (uint32_t)(fx1[i] >> 32)}; \
                 store16(dst, v);                                                               \
             } else if (fmode[i] == 1) {                                                        \
