@@ -215,8 +215,14 @@ struct Encoder {
         lead = fresh ? lz : lead;
         trail = fresh ? tz : trail;
         const uint64_t tcode = ((uint64_t)thi << 32) | tlo;
-        put((tcode << vhlen) | vh, tlen + vhlen, sink);  // <= 36 + 14 bits
-        put(pay, plen, sink);
+        const uint64_t head = (tcode << vhlen) | vh;  // <= 36 + 14 bits
+        const uint32_t hlen = tlen + vhlen;
+        if (all_lanes(hlen + plen <= 64u)) {
+            put((head << plen) | pay, hlen + plen, sink);  // one step when every lane's point fits a word (plen <= 62 then)
+        } else {
+            put(head, hlen, sink);
+            put(pay, plen, sink);
+        }
     }
 
     // close() + getLongArray(): marker, then the partial word and the trailing
