@@ -148,9 +148,15 @@ struct Encoder {
         add_next(ts_lo, 0u, v, sink);
     }
 
-    // A point that is known not to be a "first" point: straight-line code.
-    template <class Sink>
-    __device__ __forceinline__ void add_next(uint32_t ts_lo, uint32_t ts_hi, uint64_t v, Sink& sink)
+    // The codes of one point that is known not to be a "first" point: timestamp code and value
+    // header together (head, hlen <= 36 + 14 bits), then the value's payload (pay, plen).
+    struct Code {
+        uint64_t head, pay;
+        uint32_t hlen, plen;
+    };
+
+    // Works out a point's codes and moves the compressor's state past it; nothing is written.
+    __device__ __forceinline__ Code code_next(uint32_t ts_lo, uint32_t ts_hi, uint64_t v)
     {
         // ---- timestamp: code (thi:tlo) of tlen bits
         uint32_t tlo, thi, tlen;
@@ -215,13 +221,41 @@ struct Encoder {
         lead = fresh ? lz : lead;
         trail = fresh ? tz : trail;
         const uint64_t tcode = ((uint64_t)thi << 32) | tlo;
-        const uint64_t head = (tcode << vhlen) | vh;  // <= 36 + 14 bits
-        const uint32_t hlen = tlen + vhlen;
-        if (all_lanes(hlen + plen <= 64u)) {
-            put((head << plen) | pay, hlen + plen, sink);  // one step when every lane's point fits a word (plen <= 62 then)
+        return Code{(tcode << vhlen) | vh, pay, tlen + vhlen, plen};
+    }
+
+    template <class Sink>
+    __device__ __forceinline__ void emit(const Code& c, Sink& sink)
+    {
+        if (all_lanes(c.hlen + c.plen <= 64u)) {
+            put((c.head << c.plen) | c.pay, c.hlen + c.plen, sink);  // one step when every lane's point fits a word (plen <= 62 then)
         } else {
-            put(head, hlen, sink);
-            put(pay, plen, sink);
+            put(c.head, c.hlen, sink);
+            put(c.pay, c.plen, sink);
+        }
+    }
+
+    // A point that is known not to be a "first" point: straight-line code.
+    template <class Sink>
+    __device__ __forceinline__ void add_next(uint32_t ts_lo, uint32_t ts_hi, uint64_t v, Sink& sink)
+    {
+        emit(code_next(ts_lo, ts_hi, v), sink);
+    }
+
+    // Two such points.  Slowly varying series take a few bits per point: when both points of
+    // every lane fit one word together they go out in one step.
+    template <class Sink>
+    __device__ __forceinline__ void add_next2(uint32_t ts0, uint64_t v0, uint32_t ts1, uint64_t v1, Sink& sink)
+    {
+        const Code a = code_next(ts0, 0u, v0);
+        const Code b = code_next(ts1, 0u, v1);
+        const uint32_t la = a.hlen + a.plen, lb = b.hlen + b.plen;
+        if (all_lanes(la + lb <= 64u)) {
+            const uint64_t ca = (a.head << a.plen) | a.pay, cb = (b.head << b.plen) | b.pay;  // plen <= 60 in both
+            put((ca << lb) | cb, la + lb, sink);
+        } else {
+            emit(a, sink);
+            emit(b, sink);
         }
     }
 

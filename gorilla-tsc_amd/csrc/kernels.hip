@@ -395,11 +395,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
                     e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
 #else
-                    e.add_next(tl.x, 0u, lo64(va), sink);
-                    e.add_next(tl.y, 0u, hi64(va), sink);
+                    e.add_next2(tl.x, lo64(va), tl.y, hi64(va), sink);
                     if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
-                    e.add_next(tl.z, 0u, lo64(vb), sink);
-                    e.add_next(tl.w, 0u, hi64(vb), sink);
+                    e.add_next2(tl.z, lo64(vb), tl.w, hi64(vb), sink);
 #endif
                     if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
                 }
