@@ -660,12 +660,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const uint32_t off0 = d.off;                                                       \
             auto lo = [w1, w2, off0] { return WindowDecoder<FMT>::window(w1, w2, off0); };     \
             /* regular cadence in every live lane: the timestamp code is the bit '0' */        \
-            const typename WindowDecoder<FMT>::Parsed p = (lanes((int64_t)hi < 0) & active_m) == 0 \
-                ? d.template parse<true>(hi, lo) : d.template parse<false>(hi, lo);            \
+            typename WindowDecoder<FMT>::Parsed p;                                             \
+            uint64_t eos_m = 0; /* the vote is taken where the flag is made: as a flag it would \
+                                   cross the join through a vector register */                 \
+            if ((lanes((int64_t)hi < 0) & active_m) == 0) {                                    \
+                p = d.template parse<true>(hi, lo);                                            \
+            } else {                                                                           \
+                p = d.template parse<false>(hi, lo);                                           \
+                eos_m = lanes(p.eos);                                                          \
+            }                                                                                  \
             WindowDecoder<FMT> t = d;                                                          \
             t.commit(p);                                                                       \
             /* each vote is one comparison; the masks are combined as scalars */               \
-            const uint64_t rare_m = (lanes(p.eos) | (lanes(p.changed) & lanes(p.nbits == 0)) | \
+            const uint64_t rare_m = (eos_m | (lanes(p.changed) & lanes(p.nbits == 0)) |        \
                                      lanes(t.widx >= guard) | lanes(t.stored_ts == 0) |        \
                                      lanes((uint32_t)(t.stored_ts >> 32) != ts_ref)) & active_m; \
             if (GTSC_FORCE_FAST || rare_m == 0) {                                              \
