@@ -94,11 +94,14 @@ struct Encoder {
         const uint64_t va = v << ((64 - n) & 63);          // left-aligned code (n == 0: v == 0)
         const uint64_t word = acc | (va >> nacc);
         const uint64_t rest = (va << 1) << (63 - nacc);    // what did not fit (nacc == 0: nothing)
-        const uint32_t total = nacc + n;
-        const bool full = total >= 64;
+        const uint32_t total = nacc + n;                   // <= 127
+        const uint32_t full = total >> 6;                  // 1: the word is complete
         if (Sink::ALWAYS || full) sink(widx, word);  // an LDS sink takes every candidate: cheaper than a branch
-        widx += full ? 1u : 0u;
-        acc = full ? rest : word;
+        widx += full;
+        // rest is zero unless bits did not fit, so the choice between rest and word is a mask, not a
+        // select (a 64-bit select is two v_cndmask in a row, which this part executes 15 cycles slower)
+        const uint32_t keep = full - 1u;                   // all ones while the word is still open
+        acc = rest | (word & (((uint64_t)keep << 32) | keep));
         nacc = total & 63;
     }
 
@@ -548,7 +551,10 @@ struct WindowDecoder {
         const uint32_t n = c0 ? p.nbits : 0u;  // 1..64 once a window exists
         uint64_t pay = hi << p2;
         if (any_lane(p2 + n > 64)) pay |= (lo() >> 1) >> (63 - p2);  // wave-uniform: the second half of the window is needed
-        p.bits = n ? (pay >> ((64u - n) & 63u)) : 0ull;
+        // n == 0 gives 0 through a mask, not a select: two selects in a row on the condition register cost 15 cycles extra
+        const uint32_t some = (uint32_t)((int32_t)(0u - n) >> 31);  // all ones when n > 0
+        const uint64_t sh = pay >> ((64u - n) & 63u);
+        p.bits = ((uint64_t)((uint32_t)(sh >> 32) & some) << 32) | ((uint32_t)sh & some);
         p.o1 = off + clen;
         p.o2 = off + p2;
         p.o3 = p.o2 + n;
