@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
     // Completed words go to the lane's row of the ring (word w in slot w % RING_WORDS); the
     // wavefront copies them out in whole 64-byte blocks.
     uint32_t flushed = 0;  // words of this row already written to HBM (a multiple of RING_BLOCK)
+    uint32_t trigger = RING_TRIGGER;  // flushed + RING_TRIGGER: a copy is due once a row's widx reaches it
     RingSink sink{ring + lane * RING_ROW_BYTES};
     Encoder<FMT> e;
     e.widx = 0;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 dst[0] = fx0[i];                                                               \
             }                                                                                  \
         }                                                                                      \
-        if (!(FINAL)) flushed += (e.widx - flushed) & ~(RING_BLOCK - 1);                       \
+        if (!(FINAL)) { flushed += (e.widx - flushed) & ~(RING_BLOCK - 1); trigger = flushed + RING_TRIGGER; } \
         wave_sync(); /* the slots may be written again */                                      \
     }
 
@@ -396,10 +397,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
 #else
                     e.add_next2(tl.x, lo64(va), tl.y, hi64(va), sink);
-                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                     e.add_next2(tl.z, lo64(vb), tl.w, hi64(vb), sink);
 #endif
-                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
             } else {
 #pragma unroll 1
@@ -411,10 +412,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     const uint32_t zq = zbits >> (2 * q);
                     if (k < np) e.add_lo(bts_lo, tl.x, zq & 1u, lo64(va), sink);
                     if (k + 1 < np) e.add_lo(bts_lo, tl.y, (zq >> 1) & 1u, hi64(va), sink);
-                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                     if (k + 2 < np) e.add_lo(bts_lo, tl.z, (zq >> 2) & 1u, lo64(vb), sink);
                     if (k + 3 < np) e.add_lo(bts_lo, tl.w, (zq >> 3) & 1u, hi64(vb), sink);
-                    if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
             }
         } else {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 const uint32_t k = c * CH + 2 * q - phi;
                 if (k < np) e.add(bts, (int64_t)lo64(t), lo64(v), sink);
                 if (k + 1 < np) e.add(bts, (int64_t)hi64(t), hi64(v), sink);
-                if (any_lane(e.widx - flushed >= RING_TRIGGER)) GTSC_FLUSH(false)
+                if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
             }
         }
         GTSC_TICK(tk_comp)
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t nfin = 0;
     uint32_t st = 0;
     uint32_t skip = phi;               // slots of the first chunk that lie before the row's first point
-    uint32_t slow_w = valid ? 1u : 0u; // 1: this lane's next point needs the serial path (first point, zero timestamp, skip)
+    uint64_t slow_m = lanes(valid);    // wave-uniform: lanes whose next point needs the serial path (first point, zero timestamp, skip)
     uint64_t active_m = lanes(valid);  // wave-uniform: the lanes still decoding
     uint32_t ts_ref = 0;               // high half that this chunk's timestamps of the lane share
     uint32_t n0 = 0;                   // n when the chunk began
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     {                                                                                          \
         GTSC_WINDOW_READ()                                                                     \
         bool done = false;                                                                     \
-        if (lanes(slow_w != 0) == 0) {                                                         \
+        if (slow_m == 0) {                                                                     \
             const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);                     \
             const uint32_t off0 = d.off;                                                       \
             auto lo = [w1, w2, off0] { return WindowDecoder<FMT>::window(w1, w2, off0); };     \
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     GTSC_TOPUP_LAND()                                                          \
                 }                                                                              \
             }                                                                                  \
-            slow_w = (active && (skip != 0 || d.stored_ts == 0)) ? 1u : 0u;                    \
+            slow_m = lanes(skip != 0 || d.stored_ts == 0) & lanes(active);                     \
             active_m = lanes(active);                                                          \
         }                                                                                      \
     }
