@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-verify", action="store_true", help="skip the round-trip check (kernel experiments only)")
+    ap.add_argument("--format", default="v2", choices=["v2", "v1"], help="v2 = GorillaCompressor (the default), v1 = Compressor")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,11 +171,13 @@ def main():
     stream = torch.cuda.Stream(device=device)
     ctx.set_stream(stream.cuda_stream)
 
+    fmt = G.FMT_V2 if args.format == "v2" else G.FMT_V1
+
     def encode():
-        ctx.encode_device(block, ts, val, out, nw, uniform_npoints=P, uniform_slot_words=slot)
+        ctx.encode_device(block, ts, val, out, nw, uniform_npoints=P, uniform_slot_words=slot, fmt=fmt)
 
     def decode():
-        ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P)
+        ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P, fmt=fmt)
 
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
@@ -238,7 +241,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s: %d series x %d points per GPU, %s, uniform layout; step = compress + decompress" % (
-                args.workload, S, P, "v2 format"),
+                args.workload, S, P, args.format + " format"),
             "series_per_gpu": S, "points_per_series": P,
             "compressed_bits_per_point": round(64.0 * total_words / (S * P), 3),
         },
