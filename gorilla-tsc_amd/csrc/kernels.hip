@@ -1015,7 +1015,11 @@ hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         hipLaunchKernelGGL((encode_direct_kernel<FMT_V2, PRED_DFCM>), dim3(blocks), dim3(256), 0, stream, a);
-    } else if (use_direct_kernels()) {
+    } else if (use_direct_kernels() || ((((uintptr_t)a.ts ^ (uintptr_t)a.val) & 8u) != 0)) {
+        // The tiled kernel reads both arrays in 16-byte pieces laid out on the timestamps' alignment,
+        // and a piece may hold one slot beyond a series' end: harmless while the piece is 16-byte
+        // aligned (same page as the valid slot), so arrays whose addresses differ by an odd number of
+        // 8-byte words take the form that touches exactly the points.
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);

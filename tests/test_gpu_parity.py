@@ -487,3 +487,19 @@ def test_full_size_1m_series_round_trip(ctx):
     for i in range(len(idx)):
         n = int(ref_nw[i])
         assert np.array_equal(got[i, :n], ref_out[int(ref_off[i]): int(ref_off[i]) + n])
+
+
+def test_randomised_shapes_layouts_and_alignments(ctx):
+    """A slice of the sweep in tools/stress_parity.py: ragged and uniform batches of both formats in
+    arrays that start at any 8-byte phase of a line (timestamps and values on different phases
+    included, which selects the lane-per-series kernels for compression), tight and loose slots,
+    truncated images, capacities above and below the series' lengths; compressed words, decoded
+    points, counts, status words and the guard words around every array against the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "stress_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    for seed in range(1000, 1400):
+        sp.one_case(ctx, seed)
