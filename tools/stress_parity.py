@@ -16,8 +16,6 @@ import pygtsc as G
 import pyoracle as O
 from pygtsc import synth
 
-BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 FMTS = [(G.FMT_V2, O.V2), (G.FMT_V1, O.V1)]
 
 
@@ -142,6 +140,8 @@ def one_case(ctx, seed):
 
 
 def main():
+    BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     assert torch.cuda.is_available()
     ctx = G.Context(0)
     t0 = time.time()
