@@ -550,8 +550,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #define GTSC_RING_STORE(Q, BACK, W)                                                            \
     {                                                                                          \
         asm volatile("" : "+v"(Q));                                                            \
-        const uint64_t x0 = (BACK) ? hi64(Q) : lo64(Q);                                        \
-        const uint64_t x1 = (BACK) ? 0ull : hi64(Q);                                           \
+        uint64_t x0 = lo64(Q), x1 = hi64(Q);                                                   \
+        if (lanes((BACK) != 0) != 0) { /* only the last odd word of a slot comes that way */   \
+            x0 = (BACK) ? hi64(Q) : lo64(Q);                                                   \
+            x1 = (BACK) ? 0ull : hi64(Q);                                                      \
+        }                                                                                      \
         const uint32_t sl = (W) & (IN_RING_WORDS - 1);                                         \
         my_ring[sl] = x0; my_ring[sl + 1] = x1;                                                \
         if (sl == 0) { my_ring[IN_RING_WORDS] = x0; my_ring[IN_RING_WORDS + 1] = x1; }         \
