@@ -270,7 +270,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 
     const uint32_t piece = lane % PIECES;
     const uint32_t lrow = lane / PIECES;  // loader / flusher role: rows lrow + 8i
-    U4 rt[PASSES] = {}, rv[PASSES] = {};
+    U4 rt[PASSES], rv[PASSES] = {};
+#pragma unroll
+    for (uint32_t i = 0; i < PASSES; i++) rt[i] = U4{~0u, ~0u, ~0u, ~0u};  // a piece never fetched holds no zero timestamp
 
     const uint64_t cap64 = valid ? a.slots.size(s) : 0;
     const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
     GTSC_TICK(tk_fetch)
     for (uint32_t c = 0; c < nchunks; c++) {
         wave_sync();  // every lane has read the previous chunk
+        uint32_t zmin = 0xFFFFFFFFu;  // v2: 0 when one of the lane's pieces holds a zero timestamp
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) {
             const uint32_t r = lrow + i * ROWS_PER_PASS;
@@ -369,12 +372,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 uint32_t* const dst = reinterpret_cast<uint32_t*>(tile_ts + TT::addr(r, piece >> 1) + ((piece & 1) << 3));
                 dst[0] = rt[i].x;
                 dst[1] = rt[i].z;
-                const uint32_t zb = ((rt[i].x | rt[i].y) == 0 ? 1u : 0u) | ((rt[i].z | rt[i].w) == 0 ? 2u : 0u);
-                if (zb) atomicOr(&rowzero[r], zb << (2 * piece));
+                zmin = min(zmin, min(rt[i].x | rt[i].y, rt[i].z | rt[i].w));
             } else {
                 *reinterpret_cast<U4*>(tile_ts + TT::addr(r, piece)) = rt[i];
             }
             *reinterpret_cast<U4*>(tile_val + tile_addr(r, piece)) = rv[i];
+        }
+        if constexpr (FMT == FMT_V2) {
+            // a zero timestamp practically never occurs: the pieces are only looked at one by one
+            // (to mark the slot for its row) when the cheap test above has seen one
+            if (any_lane(zmin == 0)) {
+#pragma unroll
+                for (uint32_t i = 0; i < PASSES; i++) {
+                    const uint32_t zb = ((rt[i].x | rt[i].y) == 0 ? 1u : 0u) | ((rt[i].z | rt[i].w) == 0 ? 2u : 0u);
+                    if (zb) atomicOr(&rowzero[lrow + i * ROWS_PER_PASS], zb << (2 * piece));
+                }
+            }
         }
         wave_sync();
         GTSC_TICK(tk_stage)
