@@ -278,6 +278,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
     const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
     const uint64_t sbeg = valid ? a.slots.begin(s) : 0;  // the flusher lanes get it by shuffle
     const int64_t bts = valid ? a.block_ts[s] : 0;
+    // loader role: array index of slot 0 of chunk 0 of each of the lane's eight rows
+    int64_t rbase[PASSES];
+#pragma unroll
+    for (uint32_t i = 0; i < PASSES; i++) rbase[i] = (int64_t)shfl_u64(p0 - phi, lrow + i * ROWS_PER_PASS);
     // Completed words go to the lane's row of the ring (word w in slot w % RING_WORDS); the
     // wavefront copies them out in whole 64-byte blocks.
     uint32_t flushed = 0;  // words of this row already written to HBM (a multiple of RING_BLOCK)
@@ -334,15 +338,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #define GTSC_FETCH(C)                                                                          \
     {                                                                                          \
         const uint32_t v0 = (C) * CH + 2 * piece; /* first of the two slots of this piece */   \
-        U4 ri_[PASSES]; /* RowInfo as one 16-byte LDS read each, all issued before any is used */ \
-        _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++)                                \
-            ri_[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);            \
-        _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
-            const int64_t idx = (int64_t)(((uint64_t)ri_[i].y << 32) | ri_[i].x) + (int64_t)v0; \
-            if ((v0 + 1 >= ri_[i].z) & (v0 < ri_[i].w)) {                                      \
-                /* 16-byte aligned pieces of a stream that is read once */                     \
+        if (all_lanes((C) * CH >= phi && (C) * CH + CH <= phi + np)) {                         \
+            /* every row has all 16 slots of this chunk: nothing to ask the rows */            \
+            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
+                const int64_t idx = rbase[i] + (int64_t)v0;                                    \
                 rt[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.ts + idx));   \
                 rv[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx));  \
+            }                                                                                  \
+        } else {                                                                               \
+            U4 ri_[PASSES]; /* RowInfo as one 16-byte LDS read each, all issued before any is used */ \
+            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++)                            \
+                ri_[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);        \
+            _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
+                const int64_t idx = (int64_t)(((uint64_t)ri_[i].y << 32) | ri_[i].x) + (int64_t)v0; \
+                if ((v0 + 1 >= ri_[i].z) & (v0 < ri_[i].w)) {                                  \
+                    /* 16-byte aligned pieces of a stream that is read once */                 \
+                    rt[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.ts + idx)); \
+                    rv[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx)); \
+                }                                                                              \
             }                                                                                  \
         }                                                                                      \
     }
