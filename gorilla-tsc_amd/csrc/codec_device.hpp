@@ -248,10 +248,11 @@ struct Encoder {
     // Two such points.  Slowly varying series take a few bits per point: when both points of
     // every lane fit one word together they go out in one step.
     template <class Sink>
-    __device__ __forceinline__ void add_next2(uint32_t ts0, uint64_t v0, uint32_t ts1, uint64_t v1, Sink& sink)
+    __device__ __forceinline__ void add_next2(uint32_t ts0_lo, uint32_t ts0_hi, uint64_t v0,
+                                              uint32_t ts1_lo, uint32_t ts1_hi, uint64_t v1, Sink& sink)
     {
-        const Code a = code_next(ts0, 0u, v0);
-        const Code b = code_next(ts1, 0u, v1);
+        const Code a = code_next(ts0_lo, ts0_hi, v0);
+        const Code b = code_next(ts1_lo, ts1_hi, v1);
         const uint32_t la = a.hlen + a.plen, lb = b.hlen + b.plen;
         if (all_lanes(la + lb <= 64u)) {
             const uint64_t ca = (a.head << a.plen) | a.pay, cb = (b.head << b.plen) | b.pay;  // plen <= 60 in both

@@ -422,9 +422,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
                     e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
 #else
-                    e.add_next2(tl.x, lo64(va), tl.y, hi64(va), sink);
+                    e.add_next2(tl.x, 0u, lo64(va), tl.y, 0u, hi64(va), sink);
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
-                    e.add_next2(tl.z, lo64(vb), tl.w, hi64(vb), sink);
+                    e.add_next2(tl.z, 0u, lo64(vb), tl.w, 0u, hi64(vb), sink);
 #endif
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
@@ -443,6 +443,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     if (k + 3 < np) e.add_lo(bts_lo, tl.w, (zq >> 3) & 1u, hi64(vb), sink);
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
+            }
+        } else if (all_lanes(interior)) {
+            // v1, every lane has all 16 slots occupied: no guards, and pairs of ordinary points
+            // (past the first one, no zero timestamp before the second) go through together
+#pragma unroll 1
+            for (uint32_t q = 0; q < PIECES; q++) {
+                const U4 t = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q));
+                const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                if (all_lanes(e.started && lo64(t) != 0)) {
+                    e.add_next2(t.x, t.y, lo64(v), t.z, t.w, hi64(v), sink);
+                    e.started = hi64(t) != 0;
+                } else {
+                    e.add(bts, (int64_t)lo64(t), lo64(v), sink);
+                    e.add(bts, (int64_t)hi64(t), hi64(v), sink);
+                }
+                if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
             }
         } else {
 #pragma unroll 1

@@ -503,3 +503,28 @@ def test_randomised_shapes_layouts_and_alignments(ctx):
     spec.loader.exec_module(sp)
     for seed in range(1000, 1400):
         sp.one_case(ctx, seed)
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_zero_timestamps_inside_full_chunks(ctx, gfmt, ofmt):
+    """storedTimestamp == 0 makes the reference treat the next point as a first one again.  Here
+    the zeros sit in the middle of long series, at even and odd positions, in a uniform batch
+    whose chunks are all full: the kernels' unguarded paths have to notice them."""
+    S, P = 128, 96
+    rng = np.random.default_rng(5)
+    ts = 1000 * np.arange(1, P + 1, dtype=np.int64)[None, :].repeat(S, 0) + rng.integers(0, 50, size=(S, P))
+    for s in range(0, S, 3):
+        ts[s, 5 + (s % 80)] = 0
+    ts[7, 20:24] = 0
+    ts[9, 0] = 0
+    val = synth.gauge_integer(S=S, P=P, seed=3).val
+    b = synth.Batch(np.zeros(S, dtype=np.int64), np.ascontiguousarray(ts.reshape(-1)), val,
+                    np.arange(S + 1, dtype=np.uint64) * np.uint64(P))
+    for uniform in (True, False):
+        out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt, uniform=uniform)
+        gts, gval, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, gfmt)
+        rts, rval, rnp, rst = O.decode_batch(out, off, nw, b.pt_off, fmt=ofmt)
+        assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+        for s in range(S):
+            a, n = int(b.pt_off[s]), int(min(npts[s], P))
+            assert np.array_equal(gts[a:a + n], rts[a:a + n]) and np.array_equal(gval[a:a + n], rval[a:a + n])
