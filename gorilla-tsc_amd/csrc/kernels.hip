@@ -780,14 +780,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const uint32_t adt = dec_ts_addr(lane, 2 * k2);
             GTSC_POINT(0)
             if (dense) {  // a stream this dense needs a top-up per point to keep up (2 words per point at most)
-                if (lanes(pend != 0)) { if (pend) GTSC_TOPUP_LAND() }
+                if (pend) GTSC_TOPUP_LAND()
                 const bool low0 = d.widx >= limit;
-                if (any_lane(low0)) { if (low0) GTSC_TOPUP_ISSUE() }
+                if (low0) GTSC_TOPUP_ISSUE()
             }
             GTSC_POINT(1)
-            if (lanes(pend != 0)) { if (pend) GTSC_TOPUP_LAND() }
+            if (pend) GTSC_TOPUP_LAND()
             const bool low = d.widx >= limit;
-            if (any_lane(low)) { if (low) GTSC_TOPUP_ISSUE() }
+            if (low) GTSC_TOPUP_ISSUE()
         }
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
         if (active && c * DCH >= cap) { active = false; nfin = n; }
