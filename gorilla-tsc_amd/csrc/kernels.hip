@@ -592,11 +592,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #define GTSC_RING_STORE(Q, BACK, W)                                                            \
     {                                                                                          \
         asm volatile("" : "+v"(Q));                                                            \
-        uint64_t x0 = lo64(Q), x1 = hi64(Q);                                                   \
-        if (lanes((BACK) != 0) != 0) { /* only the last odd word of a slot comes that way */   \
-            x0 = (BACK) ? hi64(Q) : lo64(Q);                                                   \
-            x1 = (BACK) ? 0ull : hi64(Q);                                                      \
-        }                                                                                      \
+        /* BACK (the last odd word of a slot): the upper half moves down and the upper word is  \
+           zero -- by mask, not by select (four v_cndmask in a row cost three times their price) */ \
+        const uint32_t bm_ = 0u - (BACK);                                                      \
+        const U4 q_ = {Q.x ^ ((Q.x ^ Q.z) & bm_), Q.y ^ ((Q.y ^ Q.w) & bm_), Q.z & ~bm_, Q.w & ~bm_}; \
+        const uint64_t x0 = lo64(q_), x1 = hi64(q_);                                           \
         const uint32_t sl = (W) & (IN_RING_WORDS - 1);                                         \
         my_ring[sl] = x0; my_ring[sl + 1] = x1;                                                \
         if (sl == 0) { my_ring[IN_RING_WORDS] = x0; my_ring[IN_RING_WORDS + 1] = x1; }         \
