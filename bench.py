@@ -123,8 +123,9 @@ def pmc_traffic(workload, S, P, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps first (the GPU takes about eight of these steps to reach its steady clocks)")
     ap.add_argument("--workload", default="gauge")
     ap.add_argument("--series", type=int, default=1_000_000)
     ap.add_argument("--points", type=int, default=120)
