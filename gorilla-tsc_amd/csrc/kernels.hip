@@ -169,8 +169,12 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t x, uint32_t src_lane)
 // consecutive series.
 __device__ __forceinline__ uint64_t series_of_lane(uint32_t block, uint32_t lane, uint32_t shift)
 {
-    const uint64_t T = 1ull << shift;
-    return ((uint64_t)(block >> shift) << (6 + shift)) + (block & (T - 1)) + ((uint64_t)lane << shift);
+    // The 2^shift waves of a group share the 128-byte lines where their series meet.  Workgroups go
+    // to the 8 XCDs in turn, each with an L2 of its own: the waves of a group are 8 workgroups
+    // apart, so they run on the same XCD and a shared line is fetched (or completed) once.
+    const uint32_t r = block & ((8u << shift) - 1u);
+    const uint64_t group = ((uint64_t)(block >> (3 + shift)) << 3) + (r & 7u);
+    return (group << (6 + shift)) + (r >> 3) + ((uint64_t)lane << shift);
 }
 // shift for a layout: uniform point counts only; phase period = 16 / gcd(points mod 16, 16) series
 static uint32_t group_shift_of(const Layout& pts)
@@ -186,7 +190,8 @@ static uint32_t group_shift_of(const Layout& pts)
 static uint32_t grouped_blocks(uint64_t nseries, uint32_t shift)
 {
     const uint64_t per = 64ull << shift;
-    return (uint32_t)(((nseries + per - 1) / per) << shift);
+    const uint64_t groups = (nseries + per - 1) / per;
+    return (uint32_t)((shift ? ((groups + 7) & ~7ull) : groups) << shift);  // whole sets of 8 groups (see series_of_lane)
 }
 
 // what a loader lane needs to know about a row
