@@ -52,12 +52,20 @@ struct DeviceBuf {
 
 }  // namespace
 
+constexpr size_t FLAG_BLOCK_BYTES = 32;
+// Above this many compressed bits per point the decoder's 16-word input rings pay (measured cross-over:
+// gauges at 5 bits lose 8 %, drifting gauges at 47 bits gain 3 %, random walks and random doubles 10 %).
+constexpr uint64_t DENSE_BITS_PER_POINT = 40;
+
 struct gtsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // the one launches go to
-    uint32_t* d_flags = nullptr;    // OR of status bits raised since the last sync
+    // device block of FLAG_BLOCK_BYTES: word 0 = OR of status bits raised since the last sync; at byte 8 two
+    // 64-bit counts of what the decoder read and stored since then (compressed words, points)
+    uint32_t* d_flags = nullptr;
     uint32_t* h_flags = nullptr;    // pinned mirror
+    bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
     DeviceBuf scan_scratch;
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
     int predictor = GTSC_PRED_LAST;
@@ -139,9 +147,9 @@ int gtsc_create(int device_id, gtsc_ctx** out)
     if (!c) return fail(GTSC_ERR_ARG, "out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, FLAG_BLOCK_BYTES);
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, FLAG_BLOCK_BYTES);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, FLAG_BLOCK_BYTES, hipHostMallocDefault);
     if (e != hipSuccess) {
         int rc = fail(GTSC_ERR_HIP, "context setup: %s", hipGetErrorString(e));
         gtsc_destroy(c);
@@ -201,10 +209,14 @@ int gtsc_sync(gtsc_ctx* c)
 {
     if (int rc = check_ctx(c)) return rc;
     DeviceGuard g(c->device);
-    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, FLAG_BLOCK_BYTES, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, FLAG_BLOCK_BYTES, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t f = *c->h_flags;
+    {   // how dense were the streams decoded since the last sync: the next decodes use the ring that suits them
+        const uint64_t* counts = reinterpret_cast<const uint64_t*>(c->h_flags) + 1;
+        if (counts[1]) c->deep_ring = counts[0] * 64 > counts[1] * DENSE_BITS_PER_POINT;
+    }
     if (f & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", f);
     if (f & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series overflowed their output slot");
     return GTSC_OK;
@@ -288,7 +300,8 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
-                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u};
+                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, c->deep_ring ? 1u : 0u,
+                 reinterpret_cast<uint64_t*>(c->d_flags) + 1};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -374,8 +387,8 @@ int ensure_stage_streams(gtsc_ctx* c)
 
 int read_flags(gtsc_ctx* c, hipStream_t stream, uint32_t* out)
 {
-    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, FLAG_BLOCK_BYTES, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, FLAG_BLOCK_BYTES, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     *out = *c->h_flags;
     return GTSC_OK;
@@ -531,7 +544,8 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, st.stream));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
-                     st.status.as<uint32_t>(), c->d_flags, nullptr, c->dfcm_mask, 0u};
+                     st.status.as<uint32_t>(), c->d_flags, nullptr, c->dfcm_mask, 0u,
+                     nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u /* the host form knows the density */, nullptr};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, st.stream));
         if (np) {

@@ -18,6 +18,7 @@
 //                       stores, 5: decoder tile writes, 6: decoder ring reads, 7: both, 8: the encoder's stores
 //                       of compressed words before the last copy); results are wrong
 //   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy
+//   -DGTSC_POISON=x     the decoder's input rings start out filled with x (nothing may depend on slots never written)
 #ifndef GTSC_ABLATE
 #define GTSC_ABLATE 0
 #endif
@@ -517,9 +518,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 // already in the ring (new position < guard = loaded - 2); otherwise the exact path runs and
 // waits for the missing words.
 constexpr uint32_t DCH = CH;                      // slots per row per chunk
-constexpr uint32_t IN_RING_WORDS = 8;             // ring capacity per row
-constexpr uint32_t IN_RING_LOW = 6;               // top up while unread words <= this (2 free slots)
-constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 3) * 8;  // + mirror of slots 0 and 1 (a 3-word window never wraps) + bank padding
+//
+// The kernel exists with a ring of 8 and of 16 words.  With 8 it keeps 8 waves per CU, which is
+// what sparse streams (a few bits per point) want.  Dense streams (tens of bits per point) want
+// the words further ahead of the parser than 8 slots allow: under the decoder's own store traffic
+// a top-up takes longer than the two points between request and landing, and every landing is
+// a wait.  With 16 slots (7 waves per CU) a landing is put off until a lane is half-way through
+// its ring or the load is three checks old, which by then has arrived.  The library picks the
+// form from the density it has seen (DecodeArgs::deep_ring).
 constexpr uint32_t IN_NEVER = 0xFFFFFFFFu;        // "limit" of a lane with nothing left to load
 
 // The decoder's timestamp tile holds only the low half of each timestamp (4 bytes per slot):
@@ -539,9 +545,12 @@ struct alignas(16) DecRow {
 };
 constexpr uint32_t DEC_ROW_FULL = 16u << 8;       // info of a row with all 16 slots to flush
 
-template <int FMT>
+template <int FMT, uint32_t RING>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void decode_tiled_kernel(DecodeArgs a)
 {
+    constexpr uint32_t IN_RING_WORDS = RING;          // ring capacity per row (8 or 16)
+    constexpr uint32_t IN_RING_LOW = RING - 2;        // top up while unread words <= this (2 free slots)
+    constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 3) * 8;  // + mirror of slots 0 and 1 (a 3-word window never wraps) + bank padding
     constexpr uint32_t OFF_TS = TILE_BYTES;
     constexpr uint32_t OFF_RING = OFF_TS + DEC_TS_TILE_BYTES;
     constexpr uint32_t OFF_ROWS = OFF_RING + 64 * IN_RING_ROW_BYTES;
@@ -606,6 +615,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         my_ring[sl] = x0; my_ring[sl + 1] = x1;                                                \
         if (sl == 0) { my_ring[IN_RING_WORDS] = x0; my_ring[IN_RING_WORDS + 1] = x1; }         \
     }
+#ifdef GTSC_POISON
+    for (uint32_t i = 0; i < IN_RING_WORDS + 3; i++) my_ring[i] = GTSC_POISON;  // diagnostic build: what slots never written hold
+#endif
     // ---- initial fill: words 0..7 of the lane's own slot (separate variables, not an array: the
     // compiler would copy a whole array of quads, and wait for its loads, after every conditional load)
     uint64_t nw64 = ssz64;
@@ -630,10 +642,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     }
     // an image cannot be longer than its slot
     const uint32_t nw = nw64 > ssz ? ssz : (uint32_t)nw64;
-    uint32_t filled = IN_RING_WORDS;  // the ring holds image words [filled - 8, filled) (an even number)
+    uint32_t filled = 8;  // the ring holds image words [filled - RING, filled) that exist (an even number); 8 are loaded up front
     // wholesale commits need new widx < guard; top-ups are requested once widx >= limit
     uint32_t guard = filled >= nw ? nw : filled - 2;
-    uint32_t limit = filled >= nw ? IN_NEVER : filled - IN_RING_LOW;
+    uint32_t limit = filled >= nw ? IN_NEVER : (filled > IN_RING_LOW ? filled - IN_RING_LOW : 0u);
     if (valid) d.begin(nw, my_ring[0]);
 
     // ---- top-up state: the lane's load in flight between two checks
@@ -657,7 +669,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         GTSC_RING_STORE(tq, tback, filled)                                                     \
         filled += 2;                                                                           \
         guard = filled >= nw ? nw : filled - 2;                                                \
-        limit = (filled >= nw || !active) ? IN_NEVER : filled - IN_RING_LOW;                   \
+        limit = (filled >= nw || !active) ? IN_NEVER : (filled > IN_RING_LOW ? filled - IN_RING_LOW : 0u);                   \
         pend = 0;                                                                              \
         GTSC_TOPUP_NEXT()                                                                      \
     }
@@ -790,7 +802,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 if (low0) GTSC_TOPUP_ISSUE()
             }
             GTSC_POINT(1)
-            if (pend) GTSC_TOPUP_LAND()
+            if constexpr (RING == 8) {
+                if (pend) GTSC_TOPUP_LAND()
+            } else {
+                // pend counts the checks a top-up has been in flight: it lands when its lane is half-way
+                // through the ring or the load is three checks old (all that are in flight land with it)
+                const bool due = pend != 0 && (filled - d.widx <= RING / 2 || pend >= 3u);
+                if (any_lane(due)) { if (pend) GTSC_TOPUP_LAND() }
+                else pend += pend ? 1u : 0u;
+            }
             const bool low = d.widx >= limit;
             if (low) GTSC_TOPUP_ISSUE()
         }
@@ -880,6 +900,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         a.out_npoints[s] = n;
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
+    }
+    // What the wave read and produced: the library chooses the ring from the ratio.  One wave in 64
+    // reports (a sample is enough, and 30,000 atomics on one address would take as long as a tenth of the kernel).
+    if (a.stats && (blockIdx.x & 63u) == 0) {
+        uint32_t words = valid ? (d.widx < nw ? d.widx : nw) : 0u, points = valid ? (n < cap ? n : cap) : 0u;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) {
+            words += (uint32_t)__shfl_xor((int)words, k, 64);
+            points += (uint32_t)__shfl_xor((int)points, k, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats), (unsigned long long)words);
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 1, (unsigned long long)points);
+        }
     }
 #ifdef GTSC_STAMP
     wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
@@ -1098,8 +1132,15 @@ hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream)
         DecodeArgs g = a;
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
-        if (format == FMT_V2) hipLaunchKernelGGL(decode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, g);
-        else                  hipLaunchKernelGGL(decode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, g);
+        static const int forced = [] { const char* e = getenv("GTSC_RING"); return e ? atoi(e) : 0; }();  // tests: 8 or 16
+        const bool deep = forced ? forced == 16 : a.deep_ring != 0;
+        if (format == FMT_V2) {
+            if (deep) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 16>), dim3(blocks), dim3(64), 0, stream, g);
+            else      hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 8>), dim3(blocks), dim3(64), 0, stream, g);
+        } else {
+            if (deep) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V1, 16>), dim3(blocks), dim3(64), 0, stream, g);
+            else      hipLaunchKernelGGL((decode_tiled_kernel<FMT_V1, 8>), dim3(blocks), dim3(64), 0, stream, g);
+        }
     }
     return hipGetLastError();
 }

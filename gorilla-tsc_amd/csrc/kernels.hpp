@@ -40,6 +40,8 @@ struct DecodeArgs {
     int64_t* dfcm_tables;     // as in EncodeArgs
     uint32_t dfcm_mask;
     uint32_t group_shift;     // as in EncodeArgs
+    uint32_t deep_ring;       // nonzero: the streams are dense, use the tiled kernel's 16-word input rings
+    uint64_t* stats;          // may be null: [0] += words read, [1] += points stored
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);

@@ -1,5 +1,7 @@
 """Snapshots of open blocks and ByteBuffer byte images on the GPU, against the oracle
 (T/EncodeGorillaTest.java:483-500 testCopyFlush; G/ByteBufferBitOutput.java:42-103)."""
+import collections
+
 import numpy as np
 import pytest
 
@@ -21,9 +23,17 @@ def ctx():
     c.close()
 
 
+# The library's calls are asynchronous on its own stream.  A tensor made in an argument list dies
+# when the call returns, and torch's caching allocator hands its memory to the next allocation
+# while the kernel may still be reading it: the helper keeps the most recent uploads alive.
+_KEEP = collections.deque(maxlen=64)
+
+
 def dev(a):
     a = np.ascontiguousarray(a)
-    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+    t = torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+    _KEEP.append(t)
+    return t
 
 
 def batch():

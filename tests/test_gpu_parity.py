@@ -2,6 +2,7 @@
 CPU oracle on the same inputs -- bit-exact on compressed words, decoded
 timestamps, decoded value bits, counts and status words.  torch is used only
 to own device memory."""
+import collections
 import struct
 
 import numpy as np
@@ -26,9 +27,16 @@ def ctx():
     c.close()
 
 
+# The library's calls are asynchronous on its own stream.  A tensor made in an argument list dies
+# when the call returns, and torch's caching allocator hands its memory to the next allocation
+# while the kernel may still be reading it: the helper keeps the most recent uploads alive.
+_KEEP = collections.deque(maxlen=64)
+
+
 def dev(a, dtype=None):
-    t = torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else np.ascontiguousarray(a))
-    return t.cuda()
+    t = torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    return t
 
 
 def host_u64(t):
