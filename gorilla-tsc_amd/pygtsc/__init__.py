@@ -119,6 +119,18 @@ class Context:
         h = C.c_void_p()
         _check(lib().gtsc_create(int(device), C.byref(h)))
         self._h = h
+        # Device calls return before their kernels have run, and torch's caching allocator reuses a
+        # tensor's memory as soon as the tensor dies: every tensor handed to a device call is held
+        # here until the next sync().
+        self._held = {}
+
+    def _hold(self, *tensors):
+        for t in tensors:
+            if t is not None:
+                self._held[id(t)] = t
+        if len(self._held) > 65536:  # a caller that never calls sync(): forget the oldest half
+            for k in list(self._held)[: len(self._held) // 2]:
+                del self._held[k]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -134,12 +146,16 @@ class Context:
         _check(lib().gtsc_set_predictor(self._h, int(predictor), int(table_size)))
 
     def sync(self):
-        _check(lib().gtsc_sync(self._h))
+        try:
+            _check(lib().gtsc_sync(self._h))
+        finally:
+            self._held.clear()
 
     # ---- device-resident -------------------------------------------------
     def encode_device(self, block_ts, ts, val, out_words, out_nwords, pt_off=None, uniform_npoints=0,
                       out_off=None, uniform_slot_words=0, status=None, fmt=FMT_V2, options=0, out_nbits=None):
         S = block_ts.numel()
+        self._hold(block_ts, ts, val, out_words, out_nwords, pt_off, out_off, status, out_nbits)
         if options or out_nbits is not None:
             _check(lib().gtsc_encode_device_ex(self._h, fmt, int(options), S, _dp(block_ts), _dp(ts), _dp(val), _dp(pt_off),
                                                int(uniform_npoints), _dp(out_words), _dp(out_off), int(uniform_slot_words),
@@ -151,23 +167,27 @@ class Context:
 
     def words_to_bytes_device(self, words, nbits, out_bytes, out_nbytes, word_off=None, uniform_slot_words=0,
                               byte_off=None, uniform_slot_bytes=0):
+        self._hold(words, nbits, out_bytes, out_nbytes, word_off, byte_off)
         _check(lib().gtsc_words_to_bytes_device(self._h, nbits.numel(), _dp(words), _dp(word_off), int(uniform_slot_words),
                                                 _dp(nbits), _dp(out_bytes), _dp(byte_off), int(uniform_slot_bytes),
                                                 _dp(out_nbytes)))
 
     def bytes_to_words_device(self, data, out_words, out_nwords, nbytes=None, byte_off=None, uniform_slot_bytes=0,
                               word_off=None, uniform_slot_words=0):
+        self._hold(data, out_words, out_nwords, nbytes, byte_off, word_off)
         _check(lib().gtsc_bytes_to_words_device(self._h, out_nwords.numel(), _dp(data), _dp(byte_off), int(uniform_slot_bytes),
                                                 _dp(nbytes), _dp(out_words), _dp(word_off), int(uniform_slot_words),
                                                 _dp(out_nwords)))
 
     def decode_device(self, words, ts, val, out_npoints, nseries, in_off=None, uniform_slot_words=0, in_nwords=None,
                       pt_off=None, uniform_capacity=0, status=None, fmt=FMT_V2):
+        self._hold(words, ts, val, out_npoints, in_off, in_nwords, pt_off, status)
         _check(lib().gtsc_decode_device(self._h, fmt, int(nseries), _dp(words), _dp(in_off), int(uniform_slot_words),
                                         _dp(in_nwords), _dp(ts), _dp(val), _dp(pt_off), int(uniform_capacity),
                                         _dp(out_npoints), _dp(status)))
 
     def compact_device(self, slot_words, nwords, compact_words, compact_off, slot_off=None, uniform_slot_words=0):
+        self._hold(slot_words, nwords, compact_words, compact_off, slot_off)
         _check(lib().gtsc_compact_device(self._h, nwords.numel(), _dp(slot_words), _dp(slot_off),
                                          int(uniform_slot_words), _dp(nwords), _dp(compact_words), _dp(compact_off)))
 
