@@ -44,7 +44,7 @@ for k, cs in counters.items():
         f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2
         w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
         name = "encode" if "encode" in k else "decode" if "decode" in k else None
-        if name and "<0>" in k:
+        if name and ("<0>" in k or "<0, " in k):  # the v2 kernels (the decoder also carries its ring size)
             traffic[name + "_bytes"] = round(f + w)
             traffic[name + "_fetch_bytes"] = round(f)
             traffic[name + "_write_bytes"] = round(w)
