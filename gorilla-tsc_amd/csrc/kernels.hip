@@ -523,8 +523,8 @@ constexpr uint32_t DCH = CH;                      // slots per row per chunk
 // what sparse streams (a few bits per point) want.  Dense streams (tens of bits per point) want
 // the words further ahead of the parser than 8 slots allow: under the decoder's own store traffic
 // a top-up takes longer than the two points between request and landing, and every landing is
-// a wait.  With 16 slots (7 waves per CU) a landing is put off until a lane is half-way through
-// its ring or the load is three checks old, which by then has arrived.  The library picks the
+// a wait.  With 16 slots (7 waves per CU) a landing is put off until a lane is down to five unread
+// words or the load is five checks old, which by then has arrived.  The library picks the
 // form from the density it has seen (DecodeArgs::deep_ring).
 constexpr uint32_t IN_NEVER = 0xFFFFFFFFu;        // "limit" of a lane with nothing left to load
 
@@ -805,9 +805,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             if constexpr (RING == 8) {
                 if (pend) GTSC_TOPUP_LAND()
             } else {
-                // pend counts the checks a top-up has been in flight: it lands when its lane is half-way
-                // through the ring or the load is three checks old (all that are in flight land with it)
-                const bool due = pend != 0 && (filled - d.widx <= RING / 2 || pend >= 3u);
+                // pend counts the checks a top-up has been in flight: it lands when its lane is down to
+                // five unread words or the load is five checks old (all that are in flight land with it;
+                // measured: landing earlier waits more often, landing later starves the densest lanes)
+                const bool due = pend != 0 && (filled - d.widx <= 5u || pend >= 5u);
                 if (any_lane(due)) { if (pend) GTSC_TOPUP_LAND() }
                 else pend += pend ? 1u : 0u;
             }
