@@ -413,13 +413,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         if (c + 1 < nchunks) GTSC_FETCH(c + 1)  // in flight while this chunk is encoded
         GTSC_TICK(tk_fetch)
         const bool interior = c * CH >= phi && c * CH + CH <= phi + np;
+        const bool idle = c != 0 && c * CH >= phi + np;  // the row ended in an earlier chunk
         if constexpr (FMT == FMT_V2) {
             const uint32_t zbits = rowzero[lane];
             if (__builtin_expect(zbits != 0, 0)) rowzero[lane] = 0;
             const uint32_t bts_lo = (uint32_t)bts;
             // every lane has all 16 slots occupied, is past its first point and sees no zero
             // timestamp: no guards, no first-point test, four points per step
-            if (all_lanes(interior && e.started && zbits == 0)) {
+            // (rows that ended in an earlier chunk sit the chunk out: a batch of very unequal blocks
+            // keeps this loop for its long blocks)
+            if (all_lanes(idle || (interior && e.started && zbits == 0))) {
 #pragma unroll 1
                 for (uint32_t q = 0; q < PIECES; q += 2) {
                     const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
@@ -428,9 +431,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
                     e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
 #else
-                    e.add_next2(tl.x, 0u, lo64(va), tl.y, 0u, hi64(va), sink);
+                    if (!idle) e.add_next2(tl.x, 0u, lo64(va), tl.y, 0u, hi64(va), sink);
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
-                    e.add_next2(tl.z, 0u, lo64(vb), tl.w, 0u, hi64(vb), sink);
+                    if (!idle) e.add_next2(tl.z, 0u, lo64(vb), tl.w, 0u, hi64(vb), sink);
 #endif
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
@@ -450,19 +453,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
             }
-        } else if (all_lanes(interior)) {
+        } else if (all_lanes(interior || idle)) {
             // v1, every lane has all 16 slots occupied: no guards, and pairs of ordinary points
             // (past the first one, no zero timestamp before the second) go through together
 #pragma unroll 1
             for (uint32_t q = 0; q < PIECES; q++) {
                 const U4 t = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q));
                 const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
-                if (all_lanes(e.started && lo64(t) != 0)) {
-                    e.add_next2(t.x, t.y, lo64(v), t.z, t.w, hi64(v), sink);
-                    e.started = hi64(t) != 0;
-                } else {
-                    e.add(bts, (int64_t)lo64(t), lo64(v), sink);
-                    e.add(bts, (int64_t)hi64(t), hi64(v), sink);
+                if (!idle) {
+                    if (all_lanes(e.started && lo64(t) != 0)) {
+                        e.add_next2(t.x, t.y, lo64(v), t.z, t.w, hi64(v), sink);
+                        e.started = hi64(t) != 0;
+                    } else {
+                        e.add(bts, (int64_t)lo64(t), lo64(v), sink);
+                        e.add(bts, (int64_t)hi64(t), hi64(v), sink);
+                    }
                 }
                 if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
             }
