@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Per-step kernel times of the default workload (diagnostic): shows the steps the GPU takes to reach steady clocks."""
 import sys, os
-sys.path[:0] = ["/root/repo", "/root/repo/gorilla-tsc_amd"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gorilla-tsc_amd")]
 import torch, numpy as np
 import pygtsc as G, bench
 S, P = 1_000_000, 120
