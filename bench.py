@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-verify", action="store_true", help="skip the round-trip check (kernel experiments only)")
+    ap.add_argument("--val-phase", type=int, default=0, help="start the value array this many 8-byte words into its allocation "
+                    "(diagnostic: an odd number puts it on the other 16-byte phase than the timestamps)")
     ap.add_argument("--format", default="v2", choices=["v2", "v1"], help="v2 = GorillaCompressor (the default), v1 = Compressor")
     args = ap.parse_args()
 
@@ -161,6 +163,10 @@ def main():
 
     S, P = args.series, args.points
     block, ts, val = make_workload(args.workload, S, P, device, 0x5EED0002 + rank)
+    if args.val_phase:
+        big = torch.empty(val.numel() + args.val_phase, dtype=val.dtype, device=device)
+        big[args.val_phase:].copy_(val)
+        val = big[args.val_phase:]
     slot = args.slot_words or G.max_words(P)
     out = torch.zeros(S * slot, dtype=torch.int64, device=device)
     nw = torch.zeros(S, dtype=torch.int64, device=device)

@@ -248,7 +248,11 @@ template <int FMT> struct TsTile {
     }
 };
 
-template <int FMT>
+// SPLIT: the value array sits on another phase of a 128-byte line than the timestamp array.  The pieces
+// are laid out on the timestamps' alignment; on the other 16-byte phase a value piece straddles a 16-byte
+// boundary, and where only one of its two slots belongs to the row the other one may lie in a page that
+// is not there: such pieces are fetched slot by slot.  The value loads of this form are cached ones.
+template <int FMT, bool SPLIT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void encode_tiled_kernel(EncodeArgs a)
 {
     using TT = TsTile<FMT>;
@@ -349,7 +353,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
             _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                          \
                 const int64_t idx = rbase[i] + (int64_t)v0;                                    \
                 rt[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.ts + idx));   \
-                rv[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx));  \
+                rv[i] = SPLIT ? load16(a.val + idx)                                            \
+                              : __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx)); \
             }                                                                                  \
         } else {                                                                               \
             U4 ri_[PASSES]; /* RowInfo as one 16-byte LDS read each, all issued before any is used */ \
@@ -360,7 +365,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 if ((v0 + 1 >= ri_[i].z) & (v0 < ri_[i].w)) {                                  \
                     /* 16-byte aligned pieces of a stream that is read once */                 \
                     rt[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.ts + idx)); \
-                    rv[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx)); \
+                    if (!SPLIT) {                                                              \
+                        rv[i] = __builtin_nontemporal_load(reinterpret_cast<const U4*>(a.val + idx)); \
+                    } else {                                                                   \
+                        const bool in0 = v0 >= ri_[i].z, in1 = v0 + 1 < ri_[i].w;              \
+                        if (in0 & in1) {                                                       \
+                            rv[i] = load16(a.val + idx);                                       \
+                        } else if (in0) {                                                      \
+                            const uint64_t x = a.val[idx];                                     \
+                            rv[i].x = (uint32_t)x; rv[i].y = (uint32_t)(x >> 32);              \
+                        } else if (in1) { /* (neither: an empty row whose place falls into this piece) */ \
+                            const uint64_t x = a.val[idx + 1];                                 \
+                            rv[i].z = (uint32_t)x; rv[i].w = (uint32_t)(x >> 32);              \
+                        }                                                                      \
+                    }                                                                          \
                 }                                                                              \
             }                                                                                  \
         }                                                                                      \
@@ -1105,11 +1123,7 @@ hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         hipLaunchKernelGGL((encode_direct_kernel<FMT_V2, PRED_DFCM>), dim3(blocks), dim3(256), 0, stream, a);
-    } else if (use_direct_kernels() || ((((uintptr_t)a.ts ^ (uintptr_t)a.val) & 8u) != 0)) {
-        // The tiled kernel reads both arrays in 16-byte pieces laid out on the timestamps' alignment,
-        // and a piece may hold one slot beyond a series' end: harmless while the piece is 16-byte
-        // aligned (same page as the valid slot), so arrays whose addresses differ by an odd number of
-        // 8-byte words take the form that touches exactly the points.
+    } else if (use_direct_kernels()) {
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
@@ -1117,8 +1131,17 @@ hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
         EncodeArgs g = a;
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
-        if (format == FMT_V2) hipLaunchKernelGGL(encode_tiled_kernel<FMT_V2>, dim3(blocks), dim3(64), 0, stream, g);
-        else                  hipLaunchKernelGGL(encode_tiled_kernel<FMT_V1>, dim3(blocks), dim3(64), 0, stream, g);
+        // Arrays on different phases of a 128-byte line take the SPLIT form: needed when the addresses differ
+        // by an odd number of 8-byte words, and the better one for any other difference, because its value loads
+        // are cached ones (a row's 128 bytes of values then span two lines, each of which two chunks read).
+        const bool split = (((uintptr_t)a.ts ^ (uintptr_t)a.val) & 120u) != 0;
+        if (format == FMT_V2) {
+            if (split) hipLaunchKernelGGL((encode_tiled_kernel<FMT_V2, true>), dim3(blocks), dim3(64), 0, stream, g);
+            else       hipLaunchKernelGGL((encode_tiled_kernel<FMT_V2, false>), dim3(blocks), dim3(64), 0, stream, g);
+        } else {
+            if (split) hipLaunchKernelGGL((encode_tiled_kernel<FMT_V1, true>), dim3(blocks), dim3(64), 0, stream, g);
+            else       hipLaunchKernelGGL((encode_tiled_kernel<FMT_V1, false>), dim3(blocks), dim3(64), 0, stream, g);
+        }
     }
     return hipGetLastError();
 }
