@@ -500,7 +500,7 @@ def test_full_size_1m_series_round_trip(ctx):
 def test_randomised_shapes_layouts_and_alignments(ctx):
     """A slice of the sweep in tools/stress_parity.py: ragged and uniform batches of both formats in
     arrays that start at any 8-byte phase of a line (timestamps and values on different phases
-    included, which selects the lane-per-series kernels for compression), tight and loose slots,
+    included, which selects the compressor's form for split phases), tight and loose slots,
     truncated images, capacities above and below the series' lengths; compressed words, decoded
     points, counts, status words and the guard words around every array against the oracle."""
     import importlib.util
@@ -536,3 +536,16 @@ def test_zero_timestamps_inside_full_chunks(ctx, gfmt, ofmt):
         for s in range(S):
             a, n = int(b.pt_off[s]), int(min(npts[s], P))
             assert np.array_equal(gts[a:a + n], rts[a:a + n]) and np.array_equal(gval[a:a + n], rval[a:a + n])
+
+
+def test_lane_per_series_kernels_in_their_own_process():
+    """The plain lane-per-series kernels (both formats) are what GTSC_KERNEL=direct selects; the choice is read
+    once per process, so the sweep runs in a child process for a few seconds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTSC_KERNEL="direct")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "8", "7000"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
