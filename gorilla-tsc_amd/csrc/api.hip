@@ -42,7 +42,11 @@ struct DeviceBuf {
         if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
         size_t want = need + need / 8;
         hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { e = hipMalloc(&p, need); want = need; }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // the failed attempt must not show up as a later launch's error
+            e = hipMalloc(&p, need);
+            want = need;
+        }
         if (e == hipSuccess) bytes = want;
         return e;
     }
@@ -65,6 +69,11 @@ struct gtsc_ctx {
     // 64-bit counts of what the decoder read and stored since then (compressed words, points)
     uint32_t* d_flags = nullptr;
     uint32_t* h_flags = nullptr;    // pinned mirror
+    // The host entry points raise their status bits in a block of their own (the second
+    // FLAG_BLOCK_BYTES of the same allocations): they run on other streams than the device entry
+    // points, whose flags and counts wait for gtsc_sync() untouched.
+    uint32_t* d_flags_host = nullptr;
+    uint32_t* h_flags_host = nullptr;
     bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
     DeviceBuf scan_scratch;
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
@@ -74,7 +83,7 @@ struct gtsc_ctx {
     // staging for the host entry points, two sets for double buffering
     struct Stage {
         hipStream_t stream = nullptr;
-        DeviceBuf block_ts, ts, val, pt_off, slots, slot_off, nwords, coff, compact, status, npoints;
+        DeviceBuf block_ts, ts, val, pt_off, slots, slot_off, nwords, nbits, coff, compact, status, npoints;
     } stage[2];
 };
 
@@ -147,9 +156,13 @@ int gtsc_create(int device_id, gtsc_ctx** out)
     if (!c) return fail(GTSC_ERR_ARG, "out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, FLAG_BLOCK_BYTES);
-    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, FLAG_BLOCK_BYTES);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, FLAG_BLOCK_BYTES, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 2 * FLAG_BLOCK_BYTES);
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 2 * FLAG_BLOCK_BYTES);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 2 * FLAG_BLOCK_BYTES, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        c->d_flags_host = c->d_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
+        c->h_flags_host = c->h_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
+    }
     if (e != hipSuccess) {
         int rc = fail(GTSC_ERR_HIP, "context setup: %s", hipGetErrorString(e));
         gtsc_destroy(c);
@@ -167,7 +180,7 @@ int gtsc_destroy(gtsc_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->stage) {
         if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
-        for (DeviceBuf* b : {&s.block_ts, &s.ts, &s.val, &s.pt_off, &s.slots, &s.slot_off, &s.nwords, &s.coff,
+        for (DeviceBuf* b : {&s.block_ts, &s.ts, &s.val, &s.pt_off, &s.slots, &s.slot_off, &s.nwords, &s.nbits, &s.coff,
                              &s.compact, &s.status, &s.npoints})
             b->release();
     }
@@ -320,7 +333,6 @@ int gtsc_compact_device(gtsc_ctx* c, uint64_t nseries, const uint64_t* slot_word
     return GTSC_OK;
 }
 
-
 // ------------------------------------------------------------------------
 // Host-memory entry points: chunked, two alternating streams.
 // ------------------------------------------------------------------------
@@ -385,12 +397,13 @@ int ensure_stage_streams(gtsc_ctx* c)
     return GTSC_OK;
 }
 
+// status bits raised by the host pipeline (both of its streams are idle when this is called)
 int read_flags(gtsc_ctx* c, hipStream_t stream, uint32_t* out)
 {
-    HIP_TRY(hipMemcpyAsync(c->h_flags, c->d_flags, FLAG_BLOCK_BYTES, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemsetAsync(c->d_flags, 0, FLAG_BLOCK_BYTES, stream));
+    HIP_TRY(hipMemcpyAsync(c->h_flags_host, c->d_flags_host, FLAG_BLOCK_BYTES, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags_host, 0, FLAG_BLOCK_BYTES, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    *out = *c->h_flags;
+    *out = *c->h_flags_host;
     return GTSC_OK;
 }
 
@@ -398,12 +411,15 @@ int read_flags(gtsc_ctx* c, hipStream_t stream, uint32_t* out)
 
 extern "C" {
 
-int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* block_ts, const int64_t* ts,
-                     const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints, uint64_t* out_words,
-                     uint64_t out_capacity_words, uint64_t* out_off)
+int gtsc_encode_host_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nseries, const int64_t* block_ts,
+                        const int64_t* ts, const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints,
+                        uint64_t* out_words, uint64_t out_capacity_words, uint64_t* out_off, uint64_t* out_nbits)
 {
     if (int rc = check_ctx(c)) return rc;
     if (format != GTSC_FMT_V2 && format != GTSC_FMT_V1) return fail(GTSC_ERR_ARG, "unknown format %d", format);
+    if (options & ~(uint32_t)GTSC_ENC_NO_CLOSE) return fail(GTSC_ERR_ARG, "unknown encode options 0x%x", options);
+    if (c->predictor != GTSC_PRED_LAST && format != GTSC_FMT_V2)
+        return fail(GTSC_ERR_ARG, "only the 2.x format takes a predictor");
     if (!out_off) return fail(GTSC_ERR_ARG, "out_off must not be NULL");
     out_off[0] = 0;
     if (nseries == 0) return GTSC_OK;
@@ -470,6 +486,7 @@ int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* b
         HIP_TRY(st.slots.reserve(slot_total * 8));
         HIP_TRY(st.compact.reserve(slot_total * 8));
         HIP_TRY(st.nwords.reserve(ns * 8));
+        if (out_nbits) HIP_TRY(st.nbits.reserve(ns * 8));
         HIP_TRY(st.coff.reserve((ns + 1) * 8));
         HIP_TRY(c->scan_scratch.reserve(scan_scratch_words(CHUNK_SERIES) * 2 * sizeof(uint64_t)));
         HIP_TRY(hipMemcpyAsync(st.block_ts.p, block_ts + s0, ns * 8, hipMemcpyHostToDevice, st.stream));
@@ -479,9 +496,11 @@ int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* b
         }
         EncodeArgs a{ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
                      Layout{d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot},
-                     st.nwords.as<uint64_t>(), nullptr, c->d_flags, nullptr, 0u, nullptr, c->dfcm_mask, 0u};
+                     st.nwords.as<uint64_t>(), nullptr, c->d_flags_host, out_nbits ? st.nbits.as<uint64_t>() : nullptr,
+                     (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, nullptr, c->dfcm_mask, 0u};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_encode(a, format, st.stream));
+        if (out_nbits) HIP_TRY(hipMemcpyAsync(out_nbits + s0, st.nbits.p, ns * 8, hipMemcpyDeviceToHost, st.stream));
         uint64_t* scratch = c->scan_scratch.as<uint64_t>() + (size_t)b * scan_scratch_words(CHUNK_SERIES);
         HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), ns, st.coff.as<uint64_t>(), scratch, st.stream));
         HIP_TRY(launch_compact_copy(ns, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot}, st.nwords.as<uint64_t>(),
@@ -500,6 +519,14 @@ int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* b
                               (unsigned long long)out_capacity_words, (unsigned long long)out_off[nseries]);
     if (flags) return fail(GTSC_ERR_HIP, "internal: worst-case slot overflowed (flags 0x%x)", flags);
     return GTSC_OK;
+}
+
+int gtsc_encode_host(gtsc_ctx* c, int format, uint64_t nseries, const int64_t* block_ts, const int64_t* ts,
+                     const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints, uint64_t* out_words,
+                     uint64_t out_capacity_words, uint64_t* out_off)
+{
+    return gtsc_encode_host_ex(c, format, 0, nseries, block_ts, ts, val, pt_off, uniform_npoints, out_words,
+                               out_capacity_words, out_off, nullptr);
 }
 
 int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* words, const uint64_t* in_off,
@@ -544,7 +571,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, st.stream));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
-                     st.status.as<uint32_t>(), c->d_flags, nullptr, c->dfcm_mask, 0u,
+                     st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
                      nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u /* the host form knows the density */, nullptr};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, st.stream));

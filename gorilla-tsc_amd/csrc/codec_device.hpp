@@ -303,6 +303,11 @@ struct Decoder {
     uint32_t st;
     int64_t block_ts, stored_delta;
     uint64_t stored_ts, val;
+    // PRED_DFCM: the predictor's own last value.  The reference's decoder does not update the
+    // predictor when a value code is the single bit '0' (G/ValueDecompressor.java:53 returns
+    // predictor.predict() as it is), so after such a point the predictor lags behind the
+    // values; that is reproduced, not repaired.
+    uint64_t pred_last;
     uint32_t lead;
     int32_t trail;
 
@@ -341,7 +346,7 @@ struct Decoder {
         nwords = nwords_;
         widx = 0; off = 0;
         r0 = src(0); r1 = src(1); r2 = src(2); r3 = src(3);
-        stored_ts = 0; stored_delta = 0; val = 0;
+        stored_ts = 0; stored_delta = 0; val = 0; pred_last = 0;
         lead = NO_WINDOW; trail = 0;
         block_ts = (int64_t)r0;
         st = runs_off(64) ? ST_TRUNCATED : 0u;  // also covers nwords == 0
@@ -360,7 +365,7 @@ struct Decoder {
             if (d == 0x7FFFFFFu) return false;  // empty block
             const uint64_t v = peek_at(off + 27);
             if (runs_off(off + 91)) { st |= ST_TRUNCATED; return false; }
-            if (PRED == PRED_DFCM) dfcm.update(val, v);  // readFirst: predictor.update(value), G/ValueDecompressor.java:26-30
+            if (PRED == PRED_DFCM) { dfcm.update(pred_last, v); pred_last = v; }  // readFirst: predictor.update(value), G/ValueDecompressor.java:26-30
             val = v;
             advance(off + 91, src);
             stored_delta = (int64_t)d;
@@ -424,11 +429,19 @@ struct Decoder {
         }
         lead = nlead;
         trail = ntrail;
-        {
-            const uint64_t x = bits << ((uint32_t)ntrail & 63u);  // Java shifts by the count mod 64
-            const uint64_t v = (PRED == PRED_DFCM ? dfcm.predict(val) : val) ^ x;  // G/ValueDecompressor.java:32-54
-            if (PRED == PRED_DFCM) dfcm.update(val, v);
-            val = v;
+        if (PRED == PRED_DFCM) {
+            // G/ValueDecompressor.java:32-54: codes '10' and '11' xor the prediction and update the
+            // predictor; code '0' returns the prediction and leaves the predictor as it was
+            if (c0) {
+                const uint64_t v = dfcm.predict(pred_last) ^ (bits << ((uint32_t)ntrail & 63u));
+                dfcm.update(pred_last, v);
+                pred_last = v;
+                val = v;
+            } else {
+                val = dfcm.predict(pred_last);
+            }
+        } else {
+            val ^= bits << ((uint32_t)ntrail & 63u);  // Java shifts by the count mod 64
         }
         stored_delta = (int64_t)((uint64_t)stored_delta + (uint64_t)dd);
         stored_ts += (uint64_t)stored_delta;

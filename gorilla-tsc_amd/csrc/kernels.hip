@@ -120,6 +120,9 @@ __device__ __forceinline__ uint32_t tile_addr(uint32_t row, uint32_t piece)
 }
 
 typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+// the same 16 bytes where only 8-byte alignment is known (value arrays on the other 16-byte phase
+// than the timestamps the chunk grid is laid out on)
+typedef U4 U4a8 __attribute__((aligned(8)));
 
 // The tiled kernels run one wavefront per workgroup.  The LDS executes a wavefront's
 // instructions in order, so lanes exchanging data through LDS need no hardware wait, only
@@ -520,7 +523,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #endif
 #undef GTSC_FLUSH
     if (valid) {
-        const uint32_t st = e.widx > cap ? ST_OVERFLOW : 0u;
+        // a block beyond the tiled form's point limit was coded up to the limit: reported, not silent
+        const uint32_t st = (e.widx > cap || np64 > MAX_ROW_POINTS) ? ST_OVERFLOW : 0u;
         a.out_nwords[s] = e.widx;
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #else
                 // whole aligned lines that nothing reads again soon: streaming stores
                 __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
-                __builtin_nontemporal_store(qv[i], reinterpret_cast<U4*>(a.val + idx));
+                __builtin_nontemporal_store(qv[i], reinterpret_cast<U4a8*>(a.val + idx));
 #endif
             }
         } else {
@@ -1102,7 +1106,10 @@ __global__ __launch_bounds__(256) void compact_copy_kernel(uint64_t nseries, con
     for (uint64_t s = wave; s < nseries; s += nwaves) {
         const uint64_t* src = slot_words + slots.begin(s);
         uint64_t* d = dst + dst_off[s];
-        const uint64_t n = nwords[s];
+        // A series that overflowed its slot reports the length it would have had: only what the slot
+        // holds is there to copy (the offsets follow the reported lengths, the rest stays unwritten).
+        const uint64_t cap = slots.size(s);
+        const uint64_t n = nwords[s] < cap ? nwords[s] : cap;
         for (uint64_t i = lane; i < n; i += 64) d[i] = src[i];
     }
 }

@@ -22,7 +22,7 @@ SYMBOLS = (
     "gtsc_version", "gtsc_last_error", "gtsc_max_words", "gtsc_create", "gtsc_destroy", "gtsc_set_stream",
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
     "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
-    "gtsc_bytes_to_words_device", "gtsc_set_predictor",
+    "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex",
 )
 PRED_LAST, PRED_DFCM = 0, 1
 ENC_NO_CLOSE = 1
@@ -82,6 +82,8 @@ def lib():
     L.gtsc_compact_device.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp]
     L.gtsc_encode_host.restype = i32
     L.gtsc_encode_host.argtypes = [vp, i32, u64, vp, vp, vp, vp, u64, vp, u64, vp]
+    L.gtsc_encode_host_ex.restype = i32
+    L.gtsc_encode_host_ex.argtypes = [vp, i32, C.c_uint32, u64, vp, vp, vp, vp, u64, vp, u64, vp, vp]
     L.gtsc_decode_host.restype = i32
     L.gtsc_decode_host.argtypes = [vp, i32, u64, vp, vp, vp, vp, vp, u64, vp, vp]
     L.gtsc_host_alloc.restype = vp
@@ -186,14 +188,19 @@ class Context:
                                         _dp(in_nwords), _dp(ts), _dp(val), _dp(pt_off), int(uniform_capacity),
                                         _dp(out_npoints), _dp(status)))
 
-    def compact_device(self, slot_words, nwords, compact_words, compact_off, slot_off=None, uniform_slot_words=0):
+    def compact_device(self, slot_words, nwords, compact_words, compact_off, slot_off=None, uniform_slot_words=0,
+                       noalloc=False):
         self._hold(slot_words, nwords, compact_words, compact_off, slot_off)
-        _check(lib().gtsc_compact_device(self._h, nwords.numel(), _dp(slot_words), _dp(slot_off),
-                                         int(uniform_slot_words), _dp(nwords), _dp(compact_words), _dp(compact_off)))
+        assert not noalloc
+        f = lib().gtsc_compact_device
+        _check(f(self._h, nwords.numel(), _dp(slot_words), _dp(slot_off), int(uniform_slot_words), _dp(nwords),
+                 _dp(compact_words), _dp(compact_off)))
 
     # ---- host memory -----------------------------------------------------
-    def encode_host(self, block_ts, ts, val, pt_off=None, uniform_npoints=0, fmt=FMT_V2, capacity_words=None):
-        """numpy in, numpy out: returns (words, off) with the images back to back."""
+    def encode_host(self, block_ts, ts, val, pt_off=None, uniform_npoints=0, fmt=FMT_V2, capacity_words=None,
+                    options=0, want_nbits=False):
+        """numpy in, numpy out: returns (words, off) with the images back to back
+        (and the streams' bit lengths when want_nbits is set)."""
         block_ts = np.ascontiguousarray(block_ts, dtype=np.int64)
         ts = np.ascontiguousarray(ts, dtype=np.int64)
         val = np.ascontiguousarray(val, dtype=np.uint64)
@@ -208,6 +215,11 @@ class Context:
             capacity_words = int((bits // 64 + 2).sum())
         out = np.zeros(max(capacity_words, 1), dtype=np.uint64)
         off = np.zeros(S + 1, dtype=np.uint64)
+        if options or want_nbits:
+            nbits = np.zeros(S, dtype=np.uint64) if want_nbits else None
+            _check(lib().gtsc_encode_host_ex(self._h, fmt, int(options), S, _hp(block_ts), _hp(ts), _hp(val), _hp(pt_off),
+                                             int(uniform_npoints), _hp(out), int(capacity_words), _hp(off), _hp(nbits)))
+            return (out[: int(off[-1])], off, nbits) if want_nbits else (out[: int(off[-1])], off)
         _check(lib().gtsc_encode_host(self._h, fmt, S, _hp(block_ts), _hp(ts), _hp(val), _hp(pt_off),
                                       int(uniform_npoints), _hp(out), int(capacity_words), _hp(off)))
         return out[: int(off[-1])], off

@@ -109,7 +109,14 @@ int gtsc_sync(gtsc_ctx *ctx);
  *                                                               G/LongArrayOutput.java:141-145
  * (GTSC_FMT_V1: Compressor, G/Compressor.java:24-84.)
  * out_nwords[s] receives the image length; the image is written to
- * out_words + out_off[s] (or + s*uniform_slot_words).
+ * out_words + out_off[s] (or + s*uniform_slot_words).  A series whose image does
+ * not fit its slot gets GTSC_ST_OVERFLOW; out_nwords[s] is then the length the image
+ * would have had, and only the slot's words are written.
+ * Limits and access pattern: a block holds at most 2,147,483,392 points (longer ones are
+ * coded up to that point and flagged GTSC_ST_OVERFLOW).  The kernels fetch ts[] and val[] in
+ * aligned 16-byte pieces, so up to 8 bytes before the first and after the last point of the
+ * arrays are read (never used, never written): harmless for any allocation, since a
+ * 16-byte aligned piece cannot cross a page, but visible to a memory checker.
  */
 int gtsc_encode_device(gtsc_ctx *ctx, int format, uint64_t nseries,
                        const int64_t *block_ts,
@@ -190,7 +197,9 @@ int gtsc_decode_device(gtsc_ctx *ctx, int format, uint64_t nseries,
  * compact_off[s+1] = compact_off[s] + nwords[s], and the image of s copied to
  * compact_words + compact_off[s].  No reference counterpart (each Java block
  * owns its own long[]); this is what a caller uses to persist a batch.
- * compact_words must hold sum(nwords) words.
+ * compact_words must hold sum(nwords) words.  For a series that overflowed its slot
+ * (nwords[s] larger than the slot) only the slot's words are copied; the offsets still
+ * advance by nwords[s].
  */
 int gtsc_compact_device(gtsc_ctx *ctx, uint64_t nseries,
                         const uint64_t *slot_words,
@@ -220,6 +229,20 @@ int gtsc_encode_host(gtsc_ctx *ctx, int format, uint64_t nseries,
                      const uint64_t *pt_off, uint64_t uniform_npoints,
                      uint64_t *out_words, uint64_t out_capacity_words,
                      uint64_t *out_off);
+
+/*
+ * gtsc_encode_host with the extras of gtsc_encode_device_ex: options & GTSC_ENC_NO_CLOSE
+ * gives the snapshot getLongArray() returns before close() (G/LongArrayOutput.java:141-145,
+ * testCopyFlush); out_nbits (host array of nseries entries, may be NULL) receives each
+ * stream's length in bits, from which the ByteBufferBitOutput image is the first
+ * floor(nbits/8)+1 bytes of the words written big-endian (G/ByteBufferBitOutput.java:42-103).
+ */
+int gtsc_encode_host_ex(gtsc_ctx *ctx, int format, uint32_t options, uint64_t nseries,
+                        const int64_t *block_ts,
+                        const int64_t *ts, const uint64_t *val,
+                        const uint64_t *pt_off, uint64_t uniform_npoints,
+                        uint64_t *out_words, uint64_t out_capacity_words,
+                        uint64_t *out_off, uint64_t *out_nbits);
 
 int gtsc_decode_host(gtsc_ctx *ctx, int format, uint64_t nseries,
                      const uint64_t *words, const uint64_t *in_off,

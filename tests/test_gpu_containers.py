@@ -119,10 +119,35 @@ def test_byte_images_and_back(ctx, gfmt, ofmt):
         assert np.array_equal(d_ts.cpu().numpy(), b.ts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), b.val)
 
 
+def dfcm_decode_against_oracle(ctx, words, off, nw, pt_off, size):
+    """GPU decode with DifferentialFCM(size) against the oracle's decoder on the same images."""
+    S = len(off) - 1
+    total = int(pt_off[-1])
+    d_ts = torch.full((max(total, 1),), -7, dtype=torch.int64, device="cuda")
+    d_val = torch.full((max(total, 1),), -7, dtype=torch.int64, device="cuda")
+    d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.decode_device(dev(words), d_ts, d_val, d_np, S, in_off=dev(off), in_nwords=dev(nw), pt_off=dev(pt_off))
+    ctx.sync()
+    gts, gval, gnp = d_ts.cpu().numpy(), d_val.cpu().numpy().view(np.uint64), d_np.cpu().numpy()
+    for s in range(S):
+        a, n = int(off[s]), int(nw[s])
+        rts, rval, rc = O.decode_block(words[a:a + n], O.V2, dfcm_size=size)
+        assert rc == O.END and int(gnp[s]) == len(rts), s
+        p0 = int(pt_off[s])
+        assert np.array_equal(gts[p0:p0 + len(rts)], rts), s
+        assert np.array_equal(gval[p0:p0 + len(rts)], rval), s
+    return gts, gval
+
+
 @pytest.mark.parametrize("size", [1, 5, 128, 1024])
 def test_dfcm_predictor(ctx, size):
     """GorillaCompressor(ts, out, new DifferentialFCM(size)) per block (G/GorillaCompressor.java:34-37),
-    checked word for word against the oracle's DFCM; decoding needs the same predictor."""
+    checked word for word against the oracle's DFCM.  Decoding is checked against the oracle's
+    decoder, which follows the reference in NOT updating the predictor when a value code is the
+    single bit '0' (G/ValueDecompressor.java:53): after such a point the reference's decoder and
+    compressor disagree about the predictor's state, so DFCM blocks with a correctly predicted
+    value do not round-trip in the reference either.  The GPU reproduces that, bit for bit."""
     b = synth.ragged_mix(seed=31, nseries=130, pmax=260)
     S = b.nseries
     lens = np.diff(b.pt_off.astype(np.int64))
@@ -135,7 +160,7 @@ def test_dfcm_predictor(ctx, size):
     try:
         ctx.encode_device(dev(b.block_ts), dev(b.ts), dev(b.val), d_out, d_nw, pt_off=dev(b.pt_off), out_off=dev(slot))
         ctx.sync()
-        out, nw = d_out.cpu().numpy().view(np.uint64), d_nw.cpu().numpy()
+        out, nw = d_out.cpu().numpy().view(np.uint64), d_nw.cpu().numpy().view(np.uint64)
         differs_from_last_value = False
         for s in range(S):
             t, v = b.series(s)
@@ -144,18 +169,12 @@ def test_dfcm_predictor(ctx, size):
             plain = O.encode_block(int(b.block_ts[s]), t, v, O.V2)
             differs_from_last_value |= len(plain) != len(ref) or not np.array_equal(plain, ref)
         assert differs_from_last_value  # the predictor did take part
-        d_ts = torch.zeros(b.npoints, dtype=torch.int64, device="cuda")
-        d_val = torch.zeros(b.npoints, dtype=torch.int64, device="cuda")
-        d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
-        torch.cuda.synchronize()
-        ctx.decode_device(d_out, d_ts, d_val, d_np, S, in_off=dev(slot), in_nwords=d_nw, pt_off=dev(b.pt_off))
-        ctx.sync()
-        assert np.array_equal(d_np.cpu().numpy(), lens)
-        assert np.array_equal(d_ts.cpu().numpy(), b.ts) and np.array_equal(d_val.cpu().numpy().view(np.uint64), b.val)
+        gts, gval = dfcm_decode_against_oracle(ctx, out, slot, nw, b.pt_off, size)
+        assert np.array_equal(gts, b.ts)  # timestamps do not depend on the predictor
         # host entry points use the same predictor
         words, off = ctx.encode_host(b.block_ts, b.ts, b.val, pt_off=b.pt_off)
         ts, val, npts, st = ctx.decode_host(words, off, pt_off=b.pt_off)
-        assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+        assert np.array_equal(ts, gts) and np.array_equal(val, gval)
         s0 = 7
         ref = O.encode_block(int(b.block_ts[s0]), *b.series(s0), O.V2, dfcm_size=size)
         assert np.array_equal(words[int(off[s0]):int(off[s0 + 1])], ref)
@@ -164,3 +183,71 @@ def test_dfcm_predictor(ctx, size):
                               fmt=G.FMT_V1)
     finally:
         ctx.set_predictor(G.PRED_LAST)
+
+
+def test_dfcm_decode_follows_the_reference_decoder(ctx):
+    """Two shapes that tell a decoder that updates its predictor at every point from the
+    reference's, which does not on a '0' value code: (a) linear long series (every difference
+    repeats, so DFCM predicts exactly from the third point on), (b) series that repeat a
+    predicted value after the hash has moved.  The expected output is the oracle decoder's,
+    which is not the input: [0,10,20,30,40,50] with DifferentialFCM(8) decodes to
+    [0,10,20,20,20,20]."""
+    B = synth.BLOCK_TS
+    rng = np.random.default_rng(4)
+    series = [np.array([0, 10, 20, 30, 40, 50], dtype=np.uint64)]
+    for k in range(40):  # (a) linear, various steps and lengths
+        n = 3 + 5 * k
+        series.append((np.uint64(1000 * k) + np.uint64(7 + k) * np.arange(n, dtype=np.uint64)))
+    for k in range(40):  # (b) irregular stretches between linear ones: the hash moves, then predictions hit again
+        parts = []
+        v = int(rng.integers(0, 1 << 40))
+        for _ in range(6):
+            step = int(rng.integers(1, 1 << 20))
+            n = int(rng.integers(3, 30))
+            parts.append(v + step * np.arange(n, dtype=np.int64))
+            v = int(parts[-1][-1]) + int(rng.integers(1, 1 << 30))
+            parts.append(rng.integers(0, 1 << 52, int(rng.integers(1, 6))))
+        series.append(np.concatenate(parts).astype(np.uint64))
+    lens = [len(v) for v in series]
+    pt_off = np.zeros(len(series) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=pt_off[1:])
+    ts = np.concatenate([B + 1000 * np.arange(1, n + 1, dtype=np.int64) for n in lens])
+    val = np.concatenate(series)
+    S = len(series)
+    for size in (8, 1024):
+        ctx.set_predictor(G.PRED_DFCM, size)
+        try:
+            words, off = ctx.encode_host(np.full(S, B, dtype=np.int64), ts, val, pt_off=pt_off)
+            nw = np.diff(off.astype(np.int64)).astype(np.uint64)
+            for s in range(S):
+                ref = O.encode_block(B, ts[int(pt_off[s]):int(pt_off[s + 1])], series[s], O.V2, dfcm_size=size)
+                assert np.array_equal(words[int(off[s]):int(off[s + 1])], ref), s
+            gts, gval = dfcm_decode_against_oracle(ctx, words, off, nw, pt_off, size)
+            if size == 8:
+                assert gval[:6].tolist() == [0, 10, 20, 20, 20, 20]
+            assert not np.array_equal(gval, val)  # the reference's decoder does not give the input back here
+        finally:
+            ctx.set_predictor(G.PRED_LAST)
+
+
+def test_host_snapshots_and_bit_lengths(ctx):
+    """gtsc_encode_host_ex: open-block snapshots (testCopyFlush, T/EncodeGorillaTest.java:483-500)
+    and stream bit lengths from host memory, against the oracle; the ByteBuffer image is the first
+    floor(N/8)+1 bytes of the big-endian words."""
+    b = batch()
+    for gfmt, ofmt in FMTS:
+        for options in (0, G.ENC_NO_CLOSE):
+            words, off, nbits = ctx.encode_host(b.block_ts, b.ts, b.val, pt_off=b.pt_off, fmt=gfmt, options=options,
+                                                want_nbits=True)
+            for s in range(b.nseries):
+                t, v = b.series(s)
+                e = O.Encoder(int(b.block_ts[s]), ofmt)
+                for ti, vi in zip(t.tolist(), v.tolist()):
+                    e.add(ti, vi)
+                if not options:
+                    e.close()
+                img = words[int(off[s]):int(off[s + 1])]
+                assert int(nbits[s]) == e.nbits and np.array_equal(img, e.words()), (s, options)
+                if not options:
+                    as_bytes = img.astype(">u8").tobytes()[: int(nbits[s]) // 8 + 1]
+                    assert as_bytes == e.bytes(), s

@@ -260,6 +260,43 @@ def test_slot_overflow_is_reported(ctx):
         assert np.array_equal(out[a: a + int(nw[s])], ref_out[a: a + int(nw[s])])
 
 
+def test_compaction_after_slot_overflow(ctx):
+    """Compaction enqueued right after an encode that overflowed some slots, without a sync in
+    between: an overflowed series reports the length it would have had, and the copy must not
+    read past its slot (into the neighbour's image or past the end of the array).  Offsets follow
+    the reported lengths; series that fit are copied whole; the sync reports the overflow."""
+    b = synth.random_walk(S=200, P=500)
+    lens = np.full(200, 100, dtype=np.int64)
+    lens[::2] = G.max_words(500)
+    lens[-1] = 100  # the last series overflows too: an unclamped copy would read past the end of out_words
+    off = slot_offsets(b, tight=lens)
+    S = b.nseries
+    d_out = torch.full((int(off[-1]),), -1, dtype=torch.int64, device="cuda")
+    d_nw = torch.zeros(S, dtype=torch.int64, device="cuda")
+    d_off = dev(off)
+    ref_out, _, ref_nw, ref_st = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, out_off=off)
+    total = int(ref_nw.sum())
+    d_c = torch.full((total,), -1, dtype=torch.int64, device="cuda")
+    d_co = torch.full((S + 1,), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_device(dev(b.block_ts), dev(b.ts), dev(b.val), d_out, d_nw, pt_off=dev(b.pt_off), out_off=d_off)
+    ctx.compact_device(d_out, d_nw, d_c, d_co, slot_off=d_off)
+    with pytest.raises(G.GtscError) as ei:
+        ctx.sync()
+    assert ei.value.code == G.ERR_CAPACITY
+    nw, co, c = host_u64(d_nw), host_u64(d_co), host_u64(d_c)
+    assert np.array_equal(nw, ref_nw)
+    expect = np.zeros(S + 1, dtype=np.uint64)
+    np.cumsum(nw, out=expect[1:])
+    assert np.array_equal(co, expect)
+    fill = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for s in range(S):
+        a, n, slot = int(co[s]), int(nw[s]), int(lens[s])
+        m = min(n, slot)
+        assert np.array_equal(c[a:a + m], ref_out[int(off[s]):int(off[s]) + m]), s
+        assert np.all(c[a + m:a + n] == fill), s  # beyond the slot nothing is copied
+
+
 def test_decode_capacity_overflow_and_bad_streams(ctx):
     b = synth.random_walk(S=64, P=300)
     out, off, nw, _, _ = check_encode_against_oracle(ctx, b, G.FMT_V2, O.V2)
