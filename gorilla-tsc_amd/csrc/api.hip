@@ -74,6 +74,7 @@ struct gtsc_ctx {
     // points, whose flags and counts wait for gtsc_sync() untouched.
     uint32_t* d_flags_host = nullptr;
     uint32_t* h_flags_host = nullptr;
+    uint64_t* noalloc_scratch = nullptr;  // this device's copy of the library's static scratch array
     bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
     DeviceBuf scan_scratch;
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
@@ -163,6 +164,7 @@ int gtsc_create(int device_id, gtsc_ctx** out)
         c->d_flags_host = c->d_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
         c->h_flags_host = c->h_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
     }
+    if (e == hipSuccess) e = noalloc_scratch_of_current_device(&c->noalloc_scratch);
     if (e != hipSuccess) {
         int rc = fail(GTSC_ERR_HIP, "context setup: %s", hipGetErrorString(e));
         gtsc_destroy(c);
@@ -328,6 +330,29 @@ int gtsc_compact_device(gtsc_ctx* c, uint64_t nseries, const uint64_t* slot_word
     DeviceGuard g(c->device);
     HIP_TRY(c->scan_scratch.reserve(scan_scratch_words(nseries) * sizeof(uint64_t)));
     HIP_TRY(launch_exclusive_scan(nwords, nseries, compact_off, c->scan_scratch.as<uint64_t>(), c->stream));
+    HIP_TRY(launch_compact_copy(nseries, slot_words, Layout{slot_off, uniform_slot_words}, nwords, compact_words,
+                                compact_off, c->stream));
+    return GTSC_OK;
+}
+
+// The same compaction for callers that cannot allocate: the scan's partial sums go to the
+// library's static device array instead of a buffer of the context.  Nothing in there has to
+// start at zero (every partial sum is written before it is read), and no hipMalloc, hipFree or
+// allocating routine is called on this path.
+int gtsc_compact_device_noalloc(gtsc_ctx* c, uint64_t nseries, const uint64_t* slot_words, const uint64_t* slot_off,
+                                uint64_t uniform_slot_words, const uint64_t* nwords, uint64_t* compact_words,
+                                uint64_t* compact_off)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!compact_off) return fail(GTSC_ERR_ARG, "compact_off must not be NULL");
+    if (nseries && (!slot_words || !nwords || !compact_words)) return fail(GTSC_ERR_ARG, "slot_words/nwords/compact_words must not be NULL");
+    if (nseries > GTSC_NOALLOC_MAX_SERIES)
+        return fail(GTSC_ERR_ARG, "gtsc_compact_device_noalloc takes at most %llu series per call (got %llu)",
+                    (unsigned long long)GTSC_NOALLOC_MAX_SERIES, (unsigned long long)nseries);
+    static_assert((GTSC_NOALLOC_MAX_SERIES + 1023) / 1024 + 1 <= NOALLOC_SCRATCH_WORDS, "scratch too small for the limit");
+    if (!c->noalloc_scratch) return fail(GTSC_ERR_HIP, "the static scratch array was not found on device %d", c->device);
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_exclusive_scan(nwords, nseries, compact_off, c->noalloc_scratch, c->stream));
     HIP_TRY(launch_compact_copy(nseries, slot_words, Layout{slot_off, uniform_slot_words}, nwords, compact_words,
                                 compact_off, c->stream));
     return GTSC_OK;

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "codec_device.hpp"
 #include "kernels.hpp"
 
@@ -1204,6 +1206,31 @@ hipError_t launch_bytes_to_words(uint64_t nseries, const uint8_t* bytes, Layout 
 }
 
 uint64_t scan_scratch_words(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+
+// Scratch for the compaction entry point that allocates nothing: the partial sums of its
+// exclusive scan, one word per SCAN_TILE series.  Every GPU the library runs on holds its own
+// copy of this array, at its own address, until the process ends.  In host code the array's
+// name is only a handle for hipGetSymbolAddress; kernels get the address that call returns.
+static __device__ __align__(256) uint64_t scratch[NOALLOC_SCRATCH_WORDS];
+
+hipError_t noalloc_scratch_of_current_device(uint64_t** out)
+{
+    constexpr int MAX_DEVICES = 64;
+    static uint64_t* ptr_of[MAX_DEVICES] = {};
+    static std::mutex mu;
+    *out = nullptr;
+    int dev = -1;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of[dev]) {
+        void* p = nullptr;
+        if (hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) return e;
+        ptr_of[dev] = static_cast<uint64_t*>(p);
+    }
+    *out = ptr_of[dev];
+    return hipSuccess;
+}
 
 hipError_t launch_exclusive_scan(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* scratch, hipStream_t stream)
 {

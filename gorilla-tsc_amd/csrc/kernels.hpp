@@ -50,6 +50,10 @@ hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
 // out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); scratch holds
 // scan_scratch_words(n) words.
 uint64_t scan_scratch_words(uint64_t n);
+// The library's static device scratch array (see gtsc_compact_device_noalloc): its size in words, and
+// its address on the current device (looked up once per device, then remembered).
+constexpr uint64_t NOALLOC_SCRATCH_WORDS = 8192;
+hipError_t noalloc_scratch_of_current_device(uint64_t** out);
 hipError_t launch_exclusive_scan(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* scratch, hipStream_t stream);
 // word images <-> ByteBuffer byte images (big-endian bytes of the same bit stream)
 hipError_t launch_words_to_bytes(uint64_t nseries, const uint64_t* words, Layout wslots, const uint64_t* nbits,

@@ -22,8 +22,9 @@ SYMBOLS = (
     "gtsc_version", "gtsc_last_error", "gtsc_max_words", "gtsc_create", "gtsc_destroy", "gtsc_set_stream",
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
     "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
-    "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex",
+    "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex", "gtsc_compact_device_noalloc",
 )
+NOALLOC_MAX_SERIES = 8_000_000
 PRED_LAST, PRED_DFCM = 0, 1
 ENC_NO_CLOSE = 1
 
@@ -82,6 +83,8 @@ def lib():
     L.gtsc_compact_device.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp]
     L.gtsc_encode_host.restype = i32
     L.gtsc_encode_host.argtypes = [vp, i32, u64, vp, vp, vp, vp, u64, vp, u64, vp]
+    L.gtsc_compact_device_noalloc.restype = i32
+    L.gtsc_compact_device_noalloc.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp]
     L.gtsc_encode_host_ex.restype = i32
     L.gtsc_encode_host_ex.argtypes = [vp, i32, C.c_uint32, u64, vp, vp, vp, vp, u64, vp, u64, vp, vp]
     L.gtsc_decode_host.restype = i32
@@ -191,8 +194,7 @@ class Context:
     def compact_device(self, slot_words, nwords, compact_words, compact_off, slot_off=None, uniform_slot_words=0,
                        noalloc=False):
         self._hold(slot_words, nwords, compact_words, compact_off, slot_off)
-        assert not noalloc
-        f = lib().gtsc_compact_device
+        f = lib().gtsc_compact_device_noalloc if noalloc else lib().gtsc_compact_device
         _check(f(self._h, nwords.numel(), _dp(slot_words), _dp(slot_off), int(uniform_slot_words), _dp(nwords),
                  _dp(compact_words), _dp(compact_off)))
 

@@ -208,6 +208,24 @@ int gtsc_compact_device(gtsc_ctx *ctx, uint64_t nseries,
                         uint64_t *compact_words, uint64_t *compact_off);
 
 /*
+ * gtsc_compact_device for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in
+ * the reference.  Same arguments and results as gtsc_compact_device; the partial sums of its
+ * scan live in a static device array of the library (64 KiB, held on every GPU the library
+ * runs on until the process ends) instead of a buffer the context grows, and the call makes
+ * no hipMalloc, hipFree or other allocating call.  At most GTSC_NOALLOC_MAX_SERIES series per
+ * call (GTSC_ERR_ARG beyond).  All contexts of a GPU share the one array: calls of this entry
+ * point that overlap in time on one GPU (different streams or contexts) race; calls on one
+ * stream, or ordered by events, do not.
+ */
+#define GTSC_NOALLOC_MAX_SERIES 8000000ull
+int gtsc_compact_device_noalloc(gtsc_ctx *ctx, uint64_t nseries,
+                                const uint64_t *slot_words,
+                                const uint64_t *slot_off, uint64_t uniform_slot_words,
+                                const uint64_t *nwords,
+                                uint64_t *compact_words, uint64_t *compact_off);
+
+/*
  * Host-memory forms: every pointer is host memory and the call returns when
  * the results are in the caller's arrays.  The batch is cut into chunks of
  * whole series; each chunk is copied in, coded and copied out on one of two
