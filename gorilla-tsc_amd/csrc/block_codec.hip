@@ -1,0 +1,316 @@
+// Wave-per-block form of the Gorilla codec on gfx950: the 64 lanes of a wavefront work on 64
+// consecutive points of ONE block.  It serves batches of few and/or long blocks, where the
+// lane-per-series kernels (kernels.hip) leave most of the machine idle: a block there is a serial
+// chain walked by a single lane.
+//
+// Compressor.  Everything about a point except the value window is a function of the point and
+// its two predecessors (closed form of G/GorillaCompressor.java:49-143 and
+// G/ValueCompressor.java:32-91, G/ = src/main/java/fi/iki/yak/ts/compression/gorilla/ in the
+// reference tree), so the lanes compute delta-of-delta codes, XORs and leading/trailing zero
+// counts for 64 points at once; neighbours' values come by data-parallel-primitive moves.  The
+// window (storedLeadingZeros, storedTrailingZeros) is the one serial dependence
+// (G/ValueCompressor.java:46-50,89-90): it is wave-uniform state, and one round of the loop in
+// resolve_window() handles all points up to the next one that opens a new window.  An exclusive
+// prefix sum of the code lengths gives every code its bit position; the lanes OR their codes
+// into a staging area in LDS, and whole words leave for HBM as contiguous 8-byte stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "codec_device.hpp"
+#include "kernels.hpp"
+#include "wave_util.hpp"
+
+namespace gtsc {
+
+namespace {
+
+// Staging area of a wave: up to 63 pending bits + 64 codes of at most 114 bits = 115 words, plus the
+// two words a code may spill into.
+constexpr uint32_t STAGE_WORDS = 128;
+constexpr uint32_t BLOCK_MAX_POINTS = 0x7FFFFF00u;  // points per block (the same limit as the lane-per-series kernels)
+
+// What a lane contributes to the stream for its point: `head` (hlen <= 50 bits: timestamp code and
+// value header, or the 27-bit first delta) followed by `pay` (plen <= 64 bits); both right-aligned
+// with zeros above, both zero when their length is zero.
+struct LaneCode {
+    uint64_t head, pay;
+    uint32_t hlen, plen;
+};
+
+// Bit writer of one block, wave-uniform state: words already in HBM, bits waiting in stage[0].
+struct BlockWriter {
+    uint64_t* stage;   // LDS, STAGE_WORDS words, zero except for the pending bits in word 0
+    uint64_t* out;     // the block's slot
+    uint64_t cap;      // words in the slot
+    uint64_t wcount;   // whole words written (or dropped beyond cap) so far
+    uint32_t base;     // pending bits (< 64)
+
+    // Appends the lanes' codes in lane order and writes out the words they complete.
+    __device__ __forceinline__ void append(const LaneCode& c, uint32_t lane)
+    {
+        const uint32_t len = c.hlen + c.plen;
+        const uint32_t incl = wave_inclusive_sum(len);
+        const uint32_t total = read_lane(incl, 63);
+        const uint32_t pos = base + incl - len;       // bit position of this lane's code in the staging area
+        const uint32_t w0 = pos >> 6, sh = pos & 63;
+        // the code left-aligned in 128 bits (hi:lo)
+        const uint64_t A = c.head << ((64u - c.hlen) & 63u);
+        const uint64_t B = c.pay << ((64u - c.plen) & 63u);
+        const uint64_t hi = A | (B >> c.hlen);
+        const uint64_t lo = (B << 1) << (63u - c.hlen);
+        // ... and shifted to its place: three words at most
+        const uint64_t x0 = hi >> sh;
+        const uint64_t x1 = ((hi << 1) << (63u - sh)) | (lo >> sh);
+        const uint64_t x2 = (lo << 1) << (63u - sh);
+        unsigned long long* const st = reinterpret_cast<unsigned long long*>(stage);
+        if (x0) atomicOr(st + w0, (unsigned long long)x0);
+        if (x1) atomicOr(st + w0 + 1, (unsigned long long)x1);
+        if (x2) atomicOr(st + w0 + 2, (unsigned long long)x2);
+        const uint32_t tot = base + total;
+        const uint32_t nfull = tot >> 6;              // <= 115
+        wave_sync();
+        if (nfull) {
+            const uint64_t partial = stage[nfull];    // every lane reads the same word
+            const uint32_t k1 = lane + 64;
+            uint64_t a0 = 0, a1 = 0;
+            if (lane < nfull) a0 = stage[lane];
+            if (k1 < nfull) a1 = stage[k1];
+            wave_sync();
+            if (lane < nfull) { stage[lane] = 0; if (wcount + lane < cap) out[wcount + lane] = a0; }
+            if (k1 < nfull) { stage[k1] = 0; if (wcount + k1 < cap) out[wcount + k1] = a1; }
+            if (lane == 0) stage[nfull] = 0;
+            wave_sync();
+            if (lane == 0) stage[0] = partial;
+            wave_sync();
+        }
+        wcount += nfull;
+        base = tot & 63;
+    }
+};
+
+// The timestamp code of an ordinary point (2.x): int arithmetic on the low halves,
+// G/GorillaCompressor.java:99-143.  Returns the code (<= 36 bits) and its length.
+__device__ __forceinline__ void ts_code_v2(uint32_t t, uint32_t t1, uint32_t stored_delta, uint64_t& code, uint32_t& len)
+{
+    const uint32_t nd = t - t1;
+    const int32_t dod = (int32_t)(nd - stored_delta);
+    const uint32_t z = (((uint32_t)dod << 1) ^ (uint32_t)(dod >> 31)) - 1u;  // zigzag - 1
+    uint32_t need = 32u - (uint32_t)__clz((int)z);  // bits required; 0 when z == 0 (dod == -1)
+    need = need > 13u ? 13u : need;
+    // two bits per entry: 0 -> 36-bit code (need 0 or > 12), 1 -> '10'+7, 2 -> '110'+9, 3 -> '1110'+12
+    constexpr uint32_t BUCKET = (1u * 0x5554u) | (2u << 16) | (2u << 18) | (3u << 20) | (3u << 22) | (3u << 24);
+    const uint32_t bk = (BUCKET >> (2u * need)) & 3u;
+    constexpr uint32_t LEN = 36u | (9u << 8) | (12u << 16) | (16u << 24);
+    constexpr uint64_t PRE = 0ull | (0x100ull << 16) | (0xC00ull << 32) | (0xE000ull << 48);
+    const bool zero = dod == 0;
+    len = zero ? 1u : (LEN >> (8u * bk)) & 0xFFu;
+    const uint32_t pre = (uint32_t)(PRE >> (16u * bk)) & 0xFFFFu;
+    const uint32_t lo = zero ? 0u : (z | pre);
+    const uint32_t hi = (zero || bk != 0) ? 0u : 0xFu;
+    code = ((uint64_t)hi << 32) | lo;
+}
+
+// The same for the 1.x format: long arithmetic, two's complement payloads, G/Compressor.java:94-118.
+__device__ __forceinline__ void ts_code_v1(uint64_t t, uint64_t t1, uint64_t stored_delta, uint64_t& code, uint32_t& len)
+{
+    const uint64_t dod = (t - t1) - stored_delta;
+    const bool zero = dod == 0;
+    const bool b7 = (dod + 63u) <= 127u, b9 = (dod + 255u) <= 511u, b12 = (dod + 2047u) <= 4095u;
+    len = zero ? 1u : b7 ? 9u : b9 ? 12u : b12 ? 16u : 36u;
+    const uint32_t l = (uint32_t)dod;
+    const uint32_t lo = zero ? 0u : b7 ? (0x100u | (l & 0x7Fu)) : b9 ? (0xC00u | (l & 0x1FFu)) : b12 ? (0xE000u | (l & 0xFFFu)) : l;
+    const uint32_t hi = (zero || b7 || b9 || b12) ? 0u : 0xFu;
+    code = ((uint64_t)hi << 32) | lo;
+}
+
+// The serial part of the value codec, for 64 points at once.  A point with a nonzero XOR reuses
+// the stored window when its own leading and trailing zero counts are both at least the stored
+// ones, else it opens a new window with its own counts (G/ValueCompressor.java:46-50; no cost
+// heuristic).  (lead, trail) is the wave-uniform window on entry and on exit; every lane gets
+// the window that holds at its point (wl, wt) and whether its point opens one.  One round of the
+// loop settles all points up to the next window change.
+__device__ __forceinline__ void resolve_window(bool nz, uint32_t lz, uint32_t tz, uint32_t lane, uint32_t& lead,
+                                               uint32_t& trail, uint32_t& wl, uint32_t& wt, bool& fresh)
+{
+    uint64_t pend = lanes(nz);
+    uint64_t fresh_m = 0;
+    wl = lead; wt = trail;
+    while (pend) {
+        const uint64_t viol = lanes(nz && !(lz >= lead && tz >= trail)) & pend;
+        if (!viol) break;
+        const uint32_t j = (uint32_t)__builtin_ctzll(viol);
+        lead = read_lane(lz, j);
+        trail = read_lane(tz, j);
+        fresh_m |= 1ull << j;
+        pend &= (~1ull) << j;   // the lanes after j
+        if (lane > j) { wl = lead; wt = trail; }
+    }
+    fresh = (fresh_m >> lane) & 1u;
+}
+
+// What the wave carries from one chunk of 64 points to the next.
+struct ChunkCarry {
+    uint32_t lead, trail;       // the value window (wave-uniform)
+    uint64_t t1, t2, v1;        // the two timestamps and the value before the chunk's lane 0
+};
+
+// Codes one chunk: lane l holds point i0 + l of the block (t, v), if that is a point at all.
+template <int FMT>
+__device__ __forceinline__ void encode_chunk(BlockWriter& w, ChunkCarry& k, uint64_t t, uint64_t v, int32_t i0, uint32_t np,
+                                             int64_t bts, uint32_t lane)
+{
+    const int32_t i = i0 + (int32_t)lane;
+    const bool active = (uint32_t)i < np;
+    const uint64_t t1 = lane_shift_up(t, k.t1);
+    const uint64_t t2 = lane_shift_up(t1, k.t2);
+    const uint64_t v1 = lane_shift_up(v, k.v1);
+    k.t1 = read_lane(t, 63); k.t2 = read_lane(t1, 63); k.v1 = read_lane(v, 63);
+    // "first" is whoever follows a stored timestamp of zero (G/GorillaCompressor.java:50,65)
+    const bool first = i == 0 || t1 == 0;
+    const bool prev_first = i == 1 || t2 == 0;
+
+    uint64_t tcode = 0; uint32_t tlen = 1;  // regular cadence: the single bit '0'
+    if (FMT == FMT_V2) {
+        const uint32_t sd = (uint32_t)t1 - (prev_first ? (uint32_t)bts : (uint32_t)t2);
+        if (any_lane(active && !first && (uint32_t)t - (uint32_t)t1 != sd)) ts_code_v2((uint32_t)t, (uint32_t)t1, sd, tcode, tlen);
+    } else {
+        const uint64_t sd = t1 - (prev_first ? (uint64_t)bts : t2);
+        if (any_lane(active && !first && t - t1 != sd)) ts_code_v1(t, t1, sd, tcode, tlen);
+    }
+    const uint64_t x = v ^ v1;
+    const bool nz = active && !first && x != 0;
+    uint32_t lz = (uint32_t)__clzll((long long)x);
+    const uint32_t tz = (uint32_t)(__ffsll((long long)x) - 1);
+    if (FMT == FMT_V1) lz = lz >= 32 ? 31u : lz;           // G/Compressor.java:132-134
+    uint32_t wl, wt; bool fresh;
+    resolve_window(nz, lz, tz, lane, k.lead, k.trail, wl, wt, fresh);
+    const bool reuse = nz && !fresh;
+    const uint32_t sig = 64u - lz - tz;
+    const uint32_t vh_new = (FMT == FMT_V2) ? ((3u << 12) | (lz << 6) | (sig - 1u)) : ((3u << 11) | (lz << 6) | (sig & 63u));
+    const uint32_t vh = nz ? (reuse ? 2u : vh_new) : 0u;
+    const uint32_t vhlen = nz ? (reuse ? 2u : (FMT == FMT_V2 ? 14u : 13u)) : 1u;
+    LaneCode code;
+    code.head = active ? (tcode << vhlen) | vh : 0ull;
+    code.hlen = active ? tlen + vhlen : 0u;
+    code.pay = nz ? x >> ((reuse ? wt : tz) & 63u) : 0ull;
+    code.plen = nz ? (reuse ? 64u - wl - wt : sig) : 0u;
+    if (any_lane(active && first)) {
+        // writeFirst: 27 low bits of the delta to the block timestamp, then the raw value
+        if (active && first) {
+            code.head = (t - (uint64_t)bts) & 0x7FFFFFFull; code.hlen = 27;
+            code.pay = v; code.plen = 64;
+        }
+    }
+    w.append(code, lane);
+}
+
+// Compresses block `s` with the whole wave.
+template <int FMT>
+__device__ __forceinline__ void encode_block(const EncodeArgs& a, uint64_t s, uint64_t* stage, uint32_t lane)
+{
+    const uint64_t p0 = a.pts.begin(s), np64 = a.pts.size(s);
+    const uint32_t np = np64 > BLOCK_MAX_POINTS ? BLOCK_MAX_POINTS : (uint32_t)np64;
+    const int64_t bts = a.block_ts[s];
+    BlockWriter w{stage, a.out_words + a.slots.begin(s), a.slots.size(s), 1, 0};
+    if (lane == 0 && w.cap > 0) w.out[0] = (uint64_t)bts;  // addHeader, G/GorillaCompressor.java:39-41
+
+    // Chunks of 64 points on the 512-byte grid of the timestamp array: lane l of chunk c holds array
+    // index g0 + 64 c + l, i.e. point 64 c + l - phase of the block.
+    const uint32_t phase = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & 63u);
+    const uint32_t nchunks = np ? (uint32_t)(((uint64_t)phase + np + 63) / 64) : 0u;
+    const int64_t* const pt = a.ts + p0;
+    const uint64_t* const pv = a.val + p0;
+
+    // Three chunks are in flight in three sets of registers; a set is loaded again as soon as its
+    // chunk is coded (a rotation through one set would copy registers at the loop's end, and the
+    // copy would wait for the load just issued).  The loads are unconditional -- lanes without a
+    // point fetch the block's nearest point instead -- so that their number between any two places
+    // of the loop is fixed and a wait for one set does not have to wait for the sets issued after it.
+    uint64_t tA = 0, vA = 0, tB = 0, vB = 0, tC = 0, vC = 0;
+    const uint32_t last = np ? np - 1 : 0;
+#define GTSC_BLOCK_LOAD(C, T_, V_)                                                             \
+    {                                                                                          \
+        const uint32_t u_ = (uint32_t)(C) * 64 + lane;                                         \
+        const uint32_t d_ = u_ - phase;                                                        \
+        const uint32_t i_ = u_ < phase ? 0u : (d_ < last ? d_ : last);                         \
+        T_ = (uint64_t)__builtin_nontemporal_load(pt + i_);                                    \
+        V_ = __builtin_nontemporal_load(pv + i_);                                              \
+    }
+    if (np) {
+    GTSC_BLOCK_LOAD(0, tA, vA)
+    GTSC_BLOCK_LOAD(1, tB, vB)
+    GTSC_BLOCK_LOAD(2, tC, vC)
+    }
+    ChunkCarry k{NO_WINDOW, 0, 0, 0, 0};
+    // (a block's last round may hold one or two chunks without points: they run empty rather than
+    // branch around, again for the sake of a fixed number of loads between waits)
+    for (uint32_t c = 0; c < nchunks; c += 3) {
+        encode_chunk<FMT>(w, k, tA, vA, (int32_t)(c * 64) - (int32_t)phase, np, bts, lane);
+        GTSC_BLOCK_LOAD(c + 3, tA, vA)
+        encode_chunk<FMT>(w, k, tB, vB, (int32_t)(c * 64 + 64) - (int32_t)phase, np, bts, lane);
+        GTSC_BLOCK_LOAD(c + 4, tB, vB)
+        encode_chunk<FMT>(w, k, tC, vC, (int32_t)(c * 64 + 128) - (int32_t)phase, np, bts, lane);
+        GTSC_BLOCK_LOAD(c + 5, tC, vC)
+    }
+#undef GTSC_BLOCK_LOAD
+    uint64_t nbits = w.wcount * 64 + w.base;
+    if (!a.no_close) {
+        // close(): '1111' + 32 ones + '0' (G/GorillaCompressor.java:84-89)
+        LaneCode m{0, 0, 0, 0};
+        if (lane == 0) { m.head = 0xFFFFFFFFFull << 1; m.hlen = 37; }
+        w.append(m, lane);
+        nbits += 37;
+    }
+    // getLongArray(): the partial word (a zero word when the stream ended on a word boundary), and
+    // after close() one more zero word (G/LongArrayOutput.java:136-145)
+    const uint64_t nwords = w.wcount + (a.no_close ? 1 : 2);
+    if (lane == 0) {
+        if (w.wcount < w.cap) w.out[w.wcount] = stage[0];
+        if (!a.no_close && w.wcount + 1 < w.cap) w.out[w.wcount + 1] = 0;
+        stage[0] = 0;
+        // a block beyond the point limit was coded up to the limit: reported, not silent
+        const uint32_t st = (nwords > w.cap || np64 > BLOCK_MAX_POINTS) ? ST_OVERFLOW : 0u;
+        a.out_nwords[s] = nwords;
+        if (a.out_nbits) a.out_nbits[s] = nbits;
+        if (a.status) a.status[s] = st;
+        if (st) atomicOr(a.flags, st);
+    }
+    wave_sync();
+}
+
+// One wave per workgroup.  Wave w looks at the series w + k * gridDim.x, k < per_wave, and
+// compresses those with at least long_threshold points (the others belong to the
+// lane-per-series kernel).
+template <int FMT>
+__global__ __launch_bounds__(64) void encode_block_kernel(EncodeArgs a, uint32_t per_wave)
+{
+    __shared__ uint64_t stage[STAGE_WORDS];
+    const uint32_t lane = threadIdx.x;
+    stage[lane] = 0; stage[lane + 64] = 0;
+    wave_sync();
+    const uint64_t cand = blockIdx.x + (uint64_t)lane * gridDim.x;
+    const bool mine = lane < per_wave && cand < a.nseries && a.pts.size(cand) >= a.long_threshold;
+    uint64_t todo = lanes(mine);
+    while (todo) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        encode_block<FMT>(a, blockIdx.x + (uint64_t)j * gridDim.x, stage, lane);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream)
+{
+    if (a.nseries == 0) return hipSuccess;
+    // enough waves to fill the machine several times over when there are that many series
+    uint64_t per_wave = a.nseries / 8192;
+    per_wave = per_wave < 1 ? 1 : per_wave > 64 ? 64 : per_wave;
+    const uint32_t grid = (uint32_t)((a.nseries + per_wave - 1) / per_wave);
+    if (format == FMT_V2) hipLaunchKernelGGL(encode_block_kernel<FMT_V2>, dim3(grid), dim3(64), 0, stream, a, (uint32_t)per_wave);
+    else                  hipLaunchKernelGGL(encode_block_kernel<FMT_V1>, dim3(grid), dim3(64), 0, stream, a, (uint32_t)per_wave);
+    return hipGetLastError();
+}
+
+}  // namespace gtsc

@@ -13,6 +13,7 @@
 
 #include "codec_device.hpp"
 #include "kernels.hpp"
+#include "wave_util.hpp"
 
 // Measurement switches, never set in the shipped library:
 //   -DGTSC_STAMP        per-wave cycle stamps (s_memtime) left in the outputs, read by tools/stamps.py
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.nseries) return;
     const uint64_t p0 = a.pts.begin(s), np = a.pts.size(s);
+    if (np >= a.long_threshold) return;  // the wave-per-block kernel's
     uint64_t* out = a.out_words + a.slots.begin(s);
     const uint64_t cap = a.slots.size(s);
     const int64_t bts = a.block_ts[s];
@@ -125,17 +127,6 @@ typedef uint32_t U4 __attribute__((ext_vector_type(4)));
 // the same 16 bytes where only 8-byte alignment is known (value arrays on the other 16-byte phase
 // than the timestamps the chunk grid is laid out on)
 typedef U4 U4a8 __attribute__((aligned(8)));
-
-// The tiled kernels run one wavefront per workgroup.  The LDS executes a wavefront's
-// instructions in order, so lanes exchanging data through LDS need no hardware wait, only
-// that the compiler keeps the accesses in program order.  (__syncthreads() would also wait
-// for every outstanding global store, which costs a memory round trip per tile flush.)
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // 16-byte global access at 8-byte alignment
 __device__ __forceinline__ U4 load16(const void* p)
@@ -274,7 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 
     const uint32_t lane = threadIdx.x;
     const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
-    const bool valid = s < a.nseries;
+    const bool valid = s < a.nseries && a.pts.size(s) < a.long_threshold;  // long blocks are the wave-per-block kernel's
     const uint64_t p0 = valid ? a.pts.begin(s) : 0;
     const uint64_t np64 = valid ? a.pts.size(s) : 0;
     const uint32_t np = np64 > MAX_ROW_POINTS ? MAX_ROW_POINTS : (uint32_t)np64;
@@ -1125,9 +1116,25 @@ static bool use_direct_kernels()
     return v;
 }
 
-hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
+// Blocks of at least this many points go to the wave-per-block kernels: a lane-per-series wave
+// walks its 64 blocks in lock step, so a long block keeps its lane (and the 63 beside it) busy for
+// its whole length, while a wave-per-block kernel spends its per-block set-up on too few points
+// when blocks are short.  GTSC_LONG_POINTS overrides the threshold (tests: 0 sends every block
+// to the wave-per-block kernels, a huge number none).
+static uint64_t long_points()
 {
-    if (a.nseries == 0) return hipSuccess;
+    static const uint64_t v = [] {
+        const char* e = getenv("GTSC_LONG_POINTS");
+        return e ? strtoull(e, nullptr, 10) : 1024ull;
+    }();
+    return v;
+}
+
+hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
+{
+    if (a0.nseries == 0) return hipSuccess;
+    EncodeArgs a = a0;
+    a.long_threshold = ~0ull;
     if (a.dfcm_tables) {  // the table look-ups are per-lane global accesses anyway: direct form only
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
@@ -1136,7 +1143,19 @@ hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream)
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
+    } else if (!a.pts.off && a.pts.uniform >= long_points()) {
+        // a uniform batch of long blocks: all of it is the wave-per-block kernel's
+        a.long_threshold = 0;
+        return launch_encode_blocks(a, format, stream);
     } else {
+        // Per-series lengths are only known on the device: both kernels run over the batch, each
+        // taking the series on its side of the threshold.
+        const bool mixed = a.pts.off != nullptr;
+        if (mixed) {
+            a.long_threshold = long_points();
+            if (hipError_t e = launch_encode_blocks(a, format, stream)) return e;
+            if (a.long_threshold == 0) return hipSuccess;  // forced: nothing is left for the lanes
+        }
         EncodeArgs g = a;
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);

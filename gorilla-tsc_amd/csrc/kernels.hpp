@@ -24,6 +24,9 @@ struct EncodeArgs {
     int64_t* dfcm_tables;  // DFCM predictor: nseries zero-filled tables of dfcm_mask + 1 entries; null = last-value predictor
     uint32_t dfcm_mask;
     uint32_t group_shift;  // set by the launcher (tiled kernels): see series_of_lane()
+    // set by the launcher: series with at least this many points are coded by the wave-per-block
+    // kernel and left alone by the lane-per-series kernels (~0: no such series)
+    uint64_t long_threshold;
 };
 
 struct DecodeArgs {
@@ -45,6 +48,8 @@ struct DecodeArgs {
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);
+// wave-per-block compressor over the series of `a` with at least a.long_threshold points (block_codec.hip)
+hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
 
 // out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); scratch holds
