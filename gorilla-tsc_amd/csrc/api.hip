@@ -74,6 +74,9 @@ struct gtsc_ctx {
     // points, whose flags and counts wait for gtsc_sync() untouched.
     uint32_t* d_flags_host = nullptr;
     uint32_t* h_flags_host = nullptr;
+    // third block of the device allocation: counts of long series, one word per user
+    // (the device entry point, the two stages of the host pipeline)
+    uint64_t* d_long_count = nullptr;
     uint64_t* noalloc_scratch = nullptr;  // this device's copy of the library's static scratch array
     bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
     DeviceBuf scan_scratch;
@@ -157,12 +160,13 @@ int gtsc_create(int device_id, gtsc_ctx** out)
     if (!c) return fail(GTSC_ERR_ARG, "out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 2 * FLAG_BLOCK_BYTES);
-    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 2 * FLAG_BLOCK_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 3 * FLAG_BLOCK_BYTES);
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 3 * FLAG_BLOCK_BYTES);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 2 * FLAG_BLOCK_BYTES, hipHostMallocDefault);
     if (e == hipSuccess) {
         c->d_flags_host = c->d_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
         c->h_flags_host = c->h_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
+        c->d_long_count = reinterpret_cast<uint64_t*>(c->d_flags + 2 * FLAG_BLOCK_BYTES / sizeof(uint32_t));
     }
     if (e == hipSuccess) e = noalloc_scratch_of_current_device(&c->noalloc_scratch);
     if (e != hipSuccess) {
@@ -316,7 +320,7 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
                  out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, c->deep_ring ? 1u : 0u,
-                 reinterpret_cast<uint64_t*>(c->d_flags) + 1};
+                 reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -597,7 +601,8 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
                      st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
-                     nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u /* the host form knows the density */, nullptr};
+                     nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u /* the host form knows the density */, nullptr,
+                     ~0ull, nullptr, 0, c->d_long_count + 1 + b};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, st.stream));
         if (np) {

@@ -299,6 +299,310 @@ __global__ __launch_bounds__(64) void encode_block_kernel(EncodeArgs a, uint32_t
     }
 }
 
+
+// ------------------------------------------------------------------------
+// Decompressor.  Where a point starts is only known by decoding what precedes it, so the chain
+// of start positions is the serial part here.  It is found speculatively: the 64 lanes take the
+// 64 bit positions that follow the current one as candidate starts and each works out how long
+// a point starting there would be (timestamp bucket from the leading ones, value code from its
+// two control bits and, for a reused window, the wave-uniform window size:
+// G/GorillaDecompressor.java:74-112, G/ValueDecompressor.java:32-54).  A scalar loop then hops
+// from real start to real start through those lengths (runs of unchanged points, '00' per point,
+// in one hop).  Real starts are queued; every 64 queued points the lanes extract delta-of-deltas
+// and XOR payloads in parallel, and prefix sums / a prefix XOR over the wave turn them into
+// timestamps and values, stored as contiguous lines.
+//
+// Anything out of the ordinary -- end of the image inside a point, a reused window that was never
+// defined, a decoded timestamp of zero (which makes the reference read the next point as a
+// "first" one), more points than the caller's capacity -- hands the block to lane 0, which
+// walks on from the last point stored with the serial decoder of the lane-per-series kernels, so
+// that counts, status words and the order in which the reference's reads meet a problem are the same.
+// ------------------------------------------------------------------------
+constexpr uint32_t RING_WORDS_D = 256;   // image words staged in LDS (circular)
+constexpr uint32_t QUEUE_SLOTS = 128;    // queued point starts
+
+struct BlockDecodeLds {
+    uint64_t ring[RING_WORDS_D];
+    uint32_t qpos[QUEUE_SLOTS];   // start of a queued point, in bits from the block's committed position
+    uint32_t qwin[QUEUE_SLOTS];   // the value window in force there: significant bits | (trailing zeros & 127) << 8
+};
+
+// inclusive prefix sum / xor of 64-bit values over the wave
+template <bool XOR>
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v)
+{
+#define GTSC_SCAN_STEP(CTRL, RM)                                                               \
+    {                                                                                          \
+        const uint32_t lo_ = dpp_move<CTRL, RM>(0u, (uint32_t)v);                              \
+        const uint32_t hi_ = dpp_move<CTRL, RM>(0u, (uint32_t)(v >> 32));                      \
+        const uint64_t o_ = ((uint64_t)hi_ << 32) | lo_;                                       \
+        v = XOR ? (v ^ o_) : (v + o_);                                                         \
+    }
+    GTSC_SCAN_STEP(0x111, 0xF)
+    GTSC_SCAN_STEP(0x112, 0xF)
+    GTSC_SCAN_STEP(0x114, 0xF)
+    GTSC_SCAN_STEP(0x118, 0xF)
+    GTSC_SCAN_STEP(0x142, 0xA)
+    GTSC_SCAN_STEP(0x143, 0xC)
+#undef GTSC_SCAN_STEP
+    return v;
+}
+
+template <int FMT>
+__device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, BlockDecodeLds& lds, uint32_t lane)
+{
+    constexpr uint32_t HDR = (FMT == FMT_V2) ? 14u : 13u;
+    const uint64_t ssz64 = a.slots.size(s);
+    const uint64_t* const image = a.words + a.slots.begin(s);
+    uint64_t nw64 = a.in_nwords ? a.in_nwords[s] : ssz64;
+    if (nw64 > ssz64) nw64 = ssz64;                     // an image cannot be longer than its slot
+    const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
+    const uint64_t p0 = a.pts.begin(s);
+    const uint64_t cap = a.pts.size(s);
+    const uint64_t limit = (uint64_t)nw * 64;           // a field must end before this bit (G/LongArrayInput.java:48-52)
+
+    // ---- state at the last point handed to the output ("committed"): where the serial decoder takes over
+    uint64_t pos = 0;                 // bit position of the next unread bit
+    uint64_t n = 0;                   // points decoded
+    int64_t block_ts = 0, stored_delta = 0;
+    uint64_t stored_ts = 0, val = 0;
+    uint32_t nbits = 0;               // value window: significant bits (0: none yet) and trailing zeros
+    int32_t trail = 0;
+    bool serial = nw < 4;             // tiny images: the serial decoder from the start
+    bool finished = false;
+
+    // ---- the image through LDS: ring[w % RING_WORDS_D] holds word w for w in [filled - RING_WORDS_D, filled);
+    // words beyond the image read as zero
+    uint32_t filled = 0;
+    uint64_t inflight = 0;            // the next 64 words, requested one refill ahead
+#define GTSC_RING_REQUEST(W0) { const uint64_t w_ = (uint64_t)(W0) + lane; inflight = w_ < nw ? image[w_] : 0ull; }
+#define GTSC_RING_LAND() { lds.ring[(filled + lane) & (RING_WORDS_D - 1)] = inflight; filled += 64; GTSC_RING_REQUEST(filled) }
+    if (!serial) {
+        GTSC_RING_REQUEST(0)
+        GTSC_RING_LAND()
+        GTSC_RING_LAND()
+        wave_sync();
+        // header and first point (G/GorillaDecompressor.java:27-35,62-72): nw >= 4, so neither runs off the image
+        const uint64_t w0 = lds.ring[0], w1 = lds.ring[1], w2 = lds.ring[2];
+        block_ts = (int64_t)w0;
+        const uint32_t d = (uint32_t)(w1 >> 37);
+        if (d == 0x7FFFFFFu) {
+            finished = true;                             // empty block
+        } else {
+            val = (w1 << 27) | (w2 >> 37);
+            stored_delta = (int64_t)d;
+            stored_ts = (uint64_t)block_ts + d;
+            pos = 64 + 91;
+            n = 1;
+            if (cap == 0 || stored_ts == 0) { serial = true; pos = 64; n = 0; stored_ts = 0; stored_delta = 0; val = 0; }
+            else if (lane == 0) { a.ts[p0] = (int64_t)stored_ts; a.val[p0] = val; }
+        }
+    }
+
+    uint32_t qn = 0;                  // queued points
+    uint64_t cur = pos;               // walk position (pos is the committed one, where queue entry 0 starts)
+    uint32_t wnb = nbits; int32_t wtr = trail;   // window at the walk position
+    bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
+    bool clean_end = finished;
+
+    while (!(stop && qn == 0)) {
+        if (!stop) {
+            // ---- one span: candidates at cur + lane
+            while ((uint64_t)filled * 64 < cur + 64 * 4) { GTSC_RING_LAND() }
+            wave_sync();
+            const uint64_t b = cur + lane;
+            const uint32_t k = (uint32_t)(b >> 6), o = (uint32_t)b & 63u;
+            const uint64_t r0 = lds.ring[k & (RING_WORDS_D - 1)], r1 = lds.ring[(k + 1) & (RING_WORDS_D - 1)];
+            const uint64_t hi = WindowDecoder<FMT>::window(r0, r1, o);
+            const uint32_t top = (uint32_t)(hi >> 32);
+            uint32_t ones = (uint32_t)__clz((int)~top);
+            ones = ones > 4 ? 4u : ones;
+            constexpr uint32_t CLEN = 1u | (9u << 6) | (12u << 12) | (16u << 18) | (36u << 24);
+            const uint32_t clen = (CLEN >> (ones * 6u)) & 63u;
+            const bool eos = ones == 4 && (uint32_t)(hi >> 28) == 0xFFFFFFFFu;
+            const uint32_t xh = (uint32_t)((hi << clen) >> 32);
+            const uint32_t vtype = xh >= 0xC0000000u ? 2u : (xh >> 31);   // 0: '0', 1: '10', 2: '11'
+            uint32_t own_sig; int32_t own_trail;
+            if (FMT == FMT_V2) {
+                const uint32_t l = (xh >> 24) & 63u;
+                own_sig = ((xh >> 18) & 63u) + 1u;
+                own_trail = 64 - (int32_t)own_sig - (int32_t)l;
+            } else {
+                const uint32_t l = (xh >> 25) & 31u;
+                own_sig = (xh >> 19) & 63u;
+                own_sig = own_sig ? own_sig : 64u;
+                own_trail = 64 - (int32_t)own_sig - (int32_t)l;
+            }
+            // length of a point starting here, given the window size in force
+            const uint32_t fixed = clen + (vtype == 0 ? 1u : vtype == 1 ? 2u : HDR + own_sig);
+            uint32_t len = fixed + (vtype == 1 ? wnb : 0u);
+            uint32_t lane_nb = wnb; int32_t lane_tr = wtr;   // the window in force at this candidate
+            const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
+            uint64_t real = 0;
+            uint32_t p = 0, found = 0;
+            while (p < 64) {
+                const uint64_t here = cur + p;
+                // runs of unchanged points: '00' each
+                const uint64_t rest = span << p;
+                uint32_t zpairs = (rest ? (uint32_t)__builtin_clzll(rest) : 64u - p) >> 1;
+                if (zpairs) {
+                    const uint64_t room = limit > here ? (limit - here - 1) >> 1 : 0;   // points of 2 bits that end before the limit
+                    const uint64_t left = cap - n - qn - found;                        // and fit the capacity
+                    bool cut = false;
+                    if (zpairs > room) { zpairs = (uint32_t)room; cut = true; }
+                    if (zpairs > left) { zpairs = (uint32_t)left; cut = true; }
+                    if (zpairs) {
+                        const uint64_t m = (0x5555555555555555ull >> (64 - 2 * zpairs)) << p;   // bits p, p+2, ...
+                        real |= m;
+                        found += zpairs;
+                        p += 2 * zpairs;
+                    }
+                    if (cut) { stop = true; break; }
+                    continue;
+                }
+                const uint32_t l = read_lane(len, p);
+                const uint32_t ty = read_lane(vtype, p);
+                if (read_lane((uint32_t)eos, p)) {
+                    stop = true;
+                    clean_end = here + 36 < limit;   // the marker itself must not run off the image
+                    break;
+                }
+                if ((ty == 1 && wnb == 0) || here + l >= limit || n + qn + found >= cap) { stop = true; break; }
+                real |= 1ull << p;
+                found++;
+                if (ty == 2) {
+                    // a new window from here on: candidates that reuse the window change length
+                    wnb = read_lane(own_sig, p);
+                    wtr = (int32_t)read_lane((uint32_t)own_trail, p);
+                    len = fixed + (vtype == 1 ? wnb : 0u);
+                    if (lane > p) { lane_nb = wnb; lane_tr = wtr; }
+                }
+                p += l;
+            }
+            // queue the real starts
+            if ((real >> lane) & 1u) {
+                const uint32_t at = qn + (uint32_t)__builtin_popcountll(real & ((1ull << lane) - 1ull));
+                lds.qpos[at] = (uint32_t)(b - pos);
+                lds.qwin[at] = lane_nb | (((uint32_t)lane_tr & 127u) << 8);
+            }
+            qn += found;
+            cur += p;
+            wave_sync();
+        }
+        if (qn >= 64 || (stop && qn)) {
+            // ---- emit up to 64 queued points
+            const uint32_t m = qn < 64 ? qn : 64u;
+            const bool have = lane < m;
+            const uint32_t rel = have ? lds.qpos[lane] : 0u;
+            const uint32_t win = have ? lds.qwin[lane] : 0u;
+            const uint64_t b = pos + rel;
+            const uint32_t k = (uint32_t)(b >> 6), o = (uint32_t)b & 63u;
+            const uint64_t r0 = lds.ring[k & (RING_WORDS_D - 1)], r1 = lds.ring[(k + 1) & (RING_WORDS_D - 1)],
+                           r2 = lds.ring[(k + 2) & (RING_WORDS_D - 1)];
+            WindowDecoder<FMT> d;
+            d.off = 0; d.widx = 0; d.nwords = 0xFFFFFFFFu;
+            d.nbits = win & 255u;
+            d.trail = (int32_t)((win >> 8) & 127u);
+            d.trail = (d.trail ^ 64) - 64;   // sign-extend 7 bits
+            const uint64_t hi = WindowDecoder<FMT>::window(r0, r1, o), lo = WindowDecoder<FMT>::window(r1, r2, o);
+            const typename WindowDecoder<FMT>::Parsed q = d.template parse<false>(hi, [lo] { return lo; });
+            const uint64_t x = have ? q.bits << ((uint32_t)q.trail & 63u) : 0ull;
+            const uint64_t dd = have ? (uint64_t)q.dd : 0ull;
+            // timestamps: deltas are the running sum of the delta-of-deltas, timestamps of the deltas
+            const uint64_t delta = (uint64_t)stored_delta + wave_inclusive_scan64<false>(dd);
+            const uint64_t ts = stored_ts + wave_inclusive_scan64<false>(have ? delta : 0ull);
+            const uint64_t v = val ^ wave_inclusive_scan64<true>(x);
+            // a timestamp of exactly zero turns the next point into a "first" one: not this path's business
+            if (any_lane(have && ts == 0)) {
+                serial = true; stop = true; qn = 0;
+                break;
+            }
+            if (have) {
+                __builtin_nontemporal_store((int64_t)ts, a.ts + p0 + n + lane);
+                __builtin_nontemporal_store(v, a.val + p0 + n + lane);
+            }
+            // commit: the state after point m - 1
+            const uint32_t lastl = m - 1;
+            stored_delta = (int64_t)read_lane(delta, lastl);
+            stored_ts = read_lane(ts, lastl);
+            val = read_lane(v, lastl);
+            nbits = read_lane(q.nbits, lastl);
+            trail = (int32_t)read_lane((uint32_t)q.trail, lastl);
+            const uint32_t endrel = read_lane(rel + q.o3, lastl);
+            n += m;
+            wave_sync();
+            // the rest of the queue moves down; positions are counted from the new committed position
+            const uint32_t remain = qn - m;
+            uint32_t mp = 0, mw = 0;
+            if (lane < remain) { mp = lds.qpos[64 + lane] - endrel; mw = lds.qwin[64 + lane]; }
+            wave_sync();
+            if (lane < remain) { lds.qpos[lane] = mp; lds.qwin[lane] = mw; }
+            wave_sync();
+            qn = remain;
+            pos += endrel;
+        }
+    }
+#undef GTSC_RING_REQUEST
+#undef GTSC_RING_LAND
+    uint32_t st = 0;
+    if (!clean_end || serial) {
+        // ---- the serial decoder, lane 0, from the committed state (exact order of the reference's checks)
+        if (lane == 0) {
+            auto src = [&](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
+            Decoder<FMT> d;
+            if (nw < 4 || pos < 64) {
+                d.begin(nw, src);
+            } else {
+                d.nwords = nw;
+                d.widx = (uint32_t)(pos >> 6); d.off = (uint32_t)pos & 63u;
+                d.r0 = src(d.widx); d.r1 = src(d.widx + 1); d.r2 = src(d.widx + 2); d.r3 = src(d.widx + 3);
+                d.st = 0;
+                d.block_ts = block_ts; d.stored_delta = stored_delta; d.stored_ts = stored_ts; d.val = val; d.pred_last = 0;
+                d.lead = nbits ? (uint32_t)(64 - (int32_t)nbits - trail) : NO_WINDOW;
+                d.trail = trail;
+            }
+            int64_t t; uint64_t v;
+            while (d.next(t, v, src)) {
+                if (n < cap) { a.ts[p0 + n] = t; a.val[p0 + n] = v; } else st = ST_OVERFLOW;
+                n++;
+            }
+            st |= d.st;
+        }
+    }
+    if (lane == 0) {
+        a.out_npoints[s] = n;
+        if (a.status) a.status[s] = st;
+        if (st) atomicOr(a.flags, st);
+    }
+    wave_sync();
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64) void decode_block_kernel(DecodeArgs a, uint32_t per_wave)
+{
+    __shared__ BlockDecodeLds lds;
+    const uint32_t lane = threadIdx.x;
+    if (a.long_count && *a.long_count > a.long_max_series) return;   // too many long blocks: the lane-per-series kernel has them
+    const uint64_t cand = blockIdx.x + (uint64_t)lane * gridDim.x;
+    const bool mine = lane < per_wave && cand < a.nseries && a.pts.size(cand) >= a.long_threshold;
+    uint64_t todo = lanes(mine);
+    while (todo) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        decode_block<FMT>(a, blockIdx.x + (uint64_t)j * gridDim.x, lds, lane);
+    }
+}
+
+// How many series of the batch are "long" (capacity of at least long_threshold points): both decode
+// kernels read the count and agree on who takes them.
+__global__ __launch_bounds__(256) void count_long_kernel(uint64_t nseries, Layout pts, uint64_t long_threshold, uint64_t* count)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool is_long = s < nseries && pts.size(s) >= long_threshold;
+    const uint32_t c = (uint32_t)__builtin_popcountll(lanes(is_long));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(reinterpret_cast<unsigned long long*>(count), (unsigned long long)c);
+}
+
 }  // namespace
 
 hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream)
@@ -310,6 +614,30 @@ hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t str
     const uint32_t grid = (uint32_t)((a.nseries + per_wave - 1) / per_wave);
     if (format == FMT_V2) hipLaunchKernelGGL(encode_block_kernel<FMT_V2>, dim3(grid), dim3(64), 0, stream, a, (uint32_t)per_wave);
     else                  hipLaunchKernelGGL(encode_block_kernel<FMT_V1>, dim3(grid), dim3(64), 0, stream, a, (uint32_t)per_wave);
+    return hipGetLastError();
+}
+
+}  // namespace gtsc
+
+namespace gtsc {
+
+hipError_t launch_count_long(uint64_t nseries, Layout pts, uint64_t long_threshold, uint64_t* count, hipStream_t stream)
+{
+    if (hipError_t e = hipMemsetAsync(count, 0, sizeof(uint64_t), stream)) return e;
+    if (nseries == 0) return hipSuccess;
+    hipLaunchKernelGGL(count_long_kernel, dim3((uint32_t)((nseries + 255) / 256)), dim3(256), 0, stream, nseries, pts,
+                       long_threshold, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_blocks(const DecodeArgs& a, int format, hipStream_t stream)
+{
+    if (a.nseries == 0) return hipSuccess;
+    uint64_t per_wave = a.nseries / 8192;
+    per_wave = per_wave < 1 ? 1 : per_wave > 64 ? 64 : per_wave;
+    const uint32_t grid = (uint32_t)((a.nseries + per_wave - 1) / per_wave);
+    if (format == FMT_V2) hipLaunchKernelGGL(decode_block_kernel<FMT_V2>, dim3(grid), dim3(64), 0, stream, a, (uint32_t)per_wave);
+    else                  hipLaunchKernelGGL(decode_block_kernel<FMT_V1>, dim3(grid), dim3(64), 0, stream, a, (uint32_t)per_wave);
     return hipGetLastError();
 }
 

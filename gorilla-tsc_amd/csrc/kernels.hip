@@ -63,11 +63,18 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     if (st) atomicOr(a.flags, st);
 }
 
+// true when series s is the wave-per-block decoder's: long, and the batch holds few enough long ones
+__device__ __forceinline__ bool left_to_block_kernel(const DecodeArgs& a, uint64_t s)
+{
+    return a.pts.size(s) >= a.long_threshold && (!a.long_count || *a.long_count <= a.long_max_series);
+}
+
 template <int FMT, int PRED = PRED_LAST>
 __global__ __launch_bounds__(256) void decode_direct_kernel(DecodeArgs a)
 {
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.nseries) return;
+    if (left_to_block_kernel(a, s)) return;
     const uint64_t* in = a.words + a.slots.begin(s);
     uint64_t nw64 = a.in_nwords ? a.in_nwords[s] : a.slots.size(s);
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #endif
     const uint32_t lane = threadIdx.x;
     const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
-    const bool valid = s < a.nseries;
+    const bool valid = s < a.nseries && !left_to_block_kernel(a, s);
 #ifdef GTSC_STAMP
     uint64_t tk_pk;
     {
@@ -1174,9 +1181,39 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream)
+// The wave-per-block decompressor finds the starts of a block's points speculatively, which costs several
+// times the instructions per point of a lane-per-series wave: it pays while the long blocks of a batch are
+// too few to fill the machine with lanes (GTSC_LONG_DECODE_MAX overrides the count).
+static uint64_t long_decode_max()
 {
-    if (a.nseries == 0) return hipSuccess;
+    static const uint64_t v = [] {
+        const char* e = getenv("GTSC_LONG_DECODE_MAX");
+        return e ? strtoull(e, nullptr, 10) : 4096ull;
+    }();
+    return v;
+}
+
+hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
+{
+    if (a0.nseries == 0) return hipSuccess;
+    DecodeArgs a = a0;
+    a.long_threshold = ~0ull; a.long_count = nullptr; a.long_max_series = 0;
+    if (!a.dfcm_tables && !use_direct_kernels()) {
+        if (!a.pts.off) {
+            if (a.pts.uniform >= long_points() && a.nseries <= long_decode_max()) {
+                a.long_threshold = 0;  // a uniform batch of few long blocks: all of it is the wave-per-block kernel's
+                return launch_decode_blocks(a, format, stream);
+            }
+        } else if (a.long_count_buf) {
+            // per-series capacities are only known on the device: count the long ones, then both kernels
+            // run over the batch and each takes its side
+            a.long_threshold = long_points();
+            a.long_max_series = long_decode_max();
+            a.long_count = a.long_count_buf;
+            if (hipError_t e = launch_count_long(a.nseries, a.pts, a.long_threshold, a.long_count_buf, stream)) return e;
+            if (hipError_t e = launch_decode_blocks(a, format, stream)) return e;
+        }
+    }
     if (a.dfcm_tables) {
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);

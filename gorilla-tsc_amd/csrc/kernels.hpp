@@ -45,12 +45,22 @@ struct DecodeArgs {
     uint32_t group_shift;     // as in EncodeArgs
     uint32_t deep_ring;       // nonzero: the streams are dense, use the tiled kernel's 16-word input rings
     uint64_t* stats;          // may be null: [0] += words read, [1] += points stored
+    // Series whose capacity is at least long_threshold points are decoded by the wave-per-block kernel and left
+    // alone by the lane-per-series kernels (~0: none) -- provided the batch holds at most long_max_series of
+    // them, which both kernels read from *long_count (null: no such condition).  Set by the launcher.
+    uint64_t long_threshold;
+    const uint64_t* long_count;
+    uint64_t long_max_series;
+    uint64_t* long_count_buf; // from the caller: one device word the launcher may use for the count (may be null)
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);
 // wave-per-block compressor over the series of `a` with at least a.long_threshold points (block_codec.hip)
 hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
+// wave-per-block decompressor and the count of long series it shares with the lane-per-series kernels (block_codec.hip)
+hipError_t launch_decode_blocks(const DecodeArgs& a, int format, hipStream_t stream);
+hipError_t launch_count_long(uint64_t nseries, Layout pts, uint64_t long_threshold, uint64_t* count, hipStream_t stream);
 
 // out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); scratch holds
 // scan_scratch_words(n) words.
