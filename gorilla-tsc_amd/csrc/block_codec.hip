@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void encode_block_kernel(EncodeArgs a, uint32_t
 // walks on from the last point stored with the serial decoder of the lane-per-series kernels, so
 // that counts, status words and the order in which the reference's reads meet a problem are the same.
 // ------------------------------------------------------------------------
-constexpr uint32_t RING_WORDS_D = 256;   // image words staged in LDS (circular)
+constexpr uint32_t RING_WORDS_D = 512;   // image words staged in LDS (circular): up to 127 queued points behind, 64 candidates ahead
 constexpr uint32_t QUEUE_SLOTS = 128;    // queued point starts
 
 struct BlockDecodeLds {
@@ -407,10 +407,15 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
 
     while (!(stop && qn == 0)) {
         if (!stop) {
-            // ---- one span: candidates at cur + lane
-            while ((uint64_t)filled * 64 < cur + 64 * 4) { GTSC_RING_LAND() }
+            // ---- one step: 64 candidate starts.  Sparse streams: the 64 bit positions from cur on.
+            // Dense streams (a window of 29 bits or more): the positions cur + j * stride, where stride
+            // is the length of a point with regular cadence that reuses the window ('0' + '10' +
+            // payload) -- as long as every point is of that kind, all 64 candidates are real starts.
+            const bool strided = wnb >= 29;
+            const uint32_t stride = strided ? 3u + wnb : 1u;
+            while ((uint64_t)filled * 64 < cur + 64 * (uint64_t)stride + 64 * 4) { GTSC_RING_LAND() }
             wave_sync();
-            const uint64_t b = cur + lane;
+            const uint64_t b = cur + (uint64_t)lane * stride;
             const uint32_t k = (uint32_t)(b >> 6), o = (uint32_t)b & 63u;
             const uint64_t r0 = lds.ring[k & (RING_WORDS_D - 1)], r1 = lds.ring[(k + 1) & (RING_WORDS_D - 1)];
             const uint64_t hi = WindowDecoder<FMT>::window(r0, r1, o);
@@ -437,9 +442,38 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
             const uint32_t fixed = clen + (vtype == 0 ? 1u : vtype == 1 ? 2u : HDR + own_sig);
             uint32_t len = fixed + (vtype == 1 ? wnb : 0u);
             uint32_t lane_nb = wnb; int32_t lane_tr = wtr;   // the window in force at this candidate
-            const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
             uint64_t real = 0;
-            uint32_t p = 0, found = 0;
+            uint32_t found = 0;
+            uint64_t adv = 0;                                // bits the walk moves on by
+            if (strided) {
+                // the chain holds while every candidate has the predicted length and opens no window
+                const bool ok = !eos && vtype != 2 && len == stride && b + len < limit && n + qn + lane < cap;
+                const uint64_t bad = lanes(!ok);
+                const uint32_t js = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                found = js;
+                adv = (uint64_t)js * stride;
+                if (js < 64) {
+                    // the first candidate that differs starts where predicted, but is another kind of point
+                    const uint64_t here = cur + adv;
+                    const uint32_t l = read_lane(len, js);
+                    if (read_lane((uint32_t)eos, js)) {
+                        stop = true;
+                        clean_end = here + 36 < limit;
+                    } else if (here + l >= limit || n + qn + js >= cap) {
+                        stop = true;
+                    } else {
+                        found = js + 1;
+                        adv += l;
+                        if (read_lane(vtype, js) == 2) {
+                            wnb = read_lane(own_sig, js);
+                            wtr = (int32_t)read_lane((uint32_t)own_trail, js);
+                        }
+                    }
+                }
+                real = found >= 64 ? ~0ull : (1ull << found) - 1ull;
+            } else {
+            const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
+            uint32_t p = 0;
             while (p < 64) {
                 const uint64_t here = cur + p;
                 // runs of unchanged points: '00' each
@@ -479,6 +513,8 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                 }
                 p += l;
             }
+            adv = p;
+            }
             // queue the real starts
             if ((real >> lane) & 1u) {
                 const uint32_t at = qn + (uint32_t)__builtin_popcountll(real & ((1ull << lane) - 1ull));
@@ -486,7 +522,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                 lds.qwin[at] = lane_nb | (((uint32_t)lane_tr & 127u) << 8);
             }
             qn += found;
-            cur += p;
+            cur += adv;
             wave_sync();
         }
         if (qn >= 64 || (stop && qn)) {
