@@ -54,12 +54,36 @@ struct DeviceBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// page-locked host memory that grows (the per-chunk offset arrays of the host pipeline: a copy from
+// pageable memory would stall the stream it is enqueued on)
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        const size_t want = need + need / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 }  // namespace
 
 constexpr size_t FLAG_BLOCK_BYTES = 32;
 // Above this many compressed bits per point the decoder's 16-word input rings pay (measured cross-over:
 // gauges at 5 bits lose 8 %, drifting gauges at 47 bits gain 3 %, random walks and random doubles 10 %).
 constexpr uint64_t DENSE_BITS_PER_POINT = 40;
+
+// The host pipeline has three streams -- all copy-ins, all kernels, all copy-outs, each back to back -- and
+// NSTAGE sets of device buffers that chunks take in turn, tied together by events.  With the context's own
+// stream that makes four streams: the HIP runtime maps streams onto four hardware queues by default
+// (GPU_MAX_HW_QUEUES), and streams that share a queue run in order (a copy-in behind another chunk's kernels).
+constexpr int NSTAGE = 3;
 
 struct gtsc_ctx {
     int device = 0;
@@ -83,12 +107,15 @@ struct gtsc_ctx {
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
     int predictor = GTSC_PRED_LAST;
     uint32_t dfcm_mask = 0;
-    DeviceBuf dfcm_tables[3];  // device entry points, host stage 0, host stage 1
-    // staging for the host entry points, two sets for double buffering
+    DeviceBuf dfcm_tables[1 + NSTAGE];  // device entry points, then one per stage of the host pipeline
+    // staging for the host entry points
+    hipStream_t copy_in = nullptr, work = nullptr, copy_out = nullptr;
     struct Stage {
-        hipStream_t stream = nullptr;
+        // the chunk's input has arrived / its kernels are done / its results have left the stage's buffers
+        hipEvent_t copied_in = nullptr, coded = nullptr, drained = nullptr;
+        HostBuf h_off_a, h_off_b;   // this chunk's offset arrays, rebased to the chunk
         DeviceBuf block_ts, ts, val, pt_off, slots, slot_off, nwords, nbits, coff, compact, status, npoints;
-    } stage[2];
+    } stage[NSTAGE];
 };
 
 namespace {
@@ -184,8 +211,11 @@ int gtsc_destroy(gtsc_ctx* c)
     if (!c) return GTSC_OK;
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t q : {c->copy_in, c->work, c->copy_out})
+        if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (auto& s : c->stage) {
-        if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+        for (hipEvent_t e : {s.copied_in, s.coded, s.drained}) if (e) (void)hipEventDestroy(e);
+        s.h_off_a.release(); s.h_off_b.release();
         for (DeviceBuf* b : {&s.block_ts, &s.ts, &s.val, &s.pt_off, &s.slots, &s.slot_off, &s.nwords, &s.nbits, &s.coff,
                              &s.compact, &s.status, &s.npoints})
             b->release();
@@ -363,7 +393,7 @@ int gtsc_compact_device_noalloc(gtsc_ctx* c, uint64_t nseries, const uint64_t* s
 }
 
 // ------------------------------------------------------------------------
-// Host-memory entry points: chunked, two alternating streams.
+// Host-memory entry points: chunked, NSTAGE streams taking turns.
 // ------------------------------------------------------------------------
 void* gtsc_host_alloc(size_t bytes)
 {
@@ -384,12 +414,25 @@ void gtsc_host_free(void* p)
 
 namespace {
 
-constexpr uint64_t CHUNK_POINTS = 64ull << 20;  // 1 GiB of raw points per chunk
+// Points per chunk of the host pipeline.  Decompression of a block is a chain (where a point starts is only
+// known from the points before it), so a chunk takes at least as long as its longest block: large chunks, so
+// that the long blocks of a batch run side by side.  Compression has no such chain (a long block is spread
+// over the lanes of a wave), and smaller chunks let the copy of one chunk hide the work on the previous one.
+constexpr uint64_t CHUNK_POINTS = 64ull << 20;         // 1 GiB of raw points
+constexpr uint64_t ENCODE_CHUNK_POINTS = 16ull << 20;  // 256 MiB
 constexpr uint64_t CHUNK_SERIES = 4ull << 20;
 
 // Chunk size in points; GTSC_CHUNK_POINTS overrides it (tests use it to get many chunks from a small batch).
-uint64_t chunk_points()
+uint64_t chunk_points(bool encode)
 {
+    if (encode) {
+        static const uint64_t v = [] {
+            const char* e = getenv("GTSC_CHUNK_POINTS");
+            const uint64_t n = e ? strtoull(e, nullptr, 10) : 0;
+            return n ? (n < CHUNK_POINTS ? n : CHUNK_POINTS) : ENCODE_CHUNK_POINTS;
+        }();
+        return v;
+    }
     static const uint64_t v = [] {
         const char* e = getenv("GTSC_CHUNK_POINTS");
         const uint64_t n = e ? strtoull(e, nullptr, 10) : 0;
@@ -401,7 +444,7 @@ uint64_t chunk_points()
 struct Chunk { uint64_t s0, s1; };
 
 // cut [0, nseries) into runs of whole series of at most CHUNK_POINTS points
-std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t uniform)
+std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t uniform, bool encode)
 {
     std::vector<Chunk> out;
     uint64_t s = 0;
@@ -409,7 +452,7 @@ std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t u
         uint64_t e = s, pts = 0;
         while (e < nseries && e - s < CHUNK_SERIES) {
             const uint64_t n = off ? off[e + 1] - off[e] : uniform;
-            if (e > s && pts + n > chunk_points()) break;
+            if (e > s && pts + n > chunk_points(encode)) break;
             pts += n;
             e++;
         }
@@ -421,8 +464,11 @@ std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t u
 
 int ensure_stage_streams(gtsc_ctx* c)
 {
+    for (hipStream_t* q : {&c->copy_in, &c->work, &c->copy_out})
+        if (!*q) HIP_TRY(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
     for (auto& st : c->stage)
-        if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&st.copied_in, &st.coded, &st.drained})
+            if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return GTSC_OK;
 }
 
@@ -457,93 +503,96 @@ int gtsc_encode_host_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nser
     DeviceGuard g(c->device);
     if (int rc = ensure_stage_streams(c)) return rc;
 
-    const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_npoints);
-    std::vector<uint64_t> rebased[2], slot_off[2];
-    struct Pending { bool live = false; uint64_t s0 = 0, s1 = 0; } pending[2];
-    uint64_t base = 0;      // words produced by the chunks completed so far
-    bool overflow = false;
-
-    // finish a chunk: learn its size, then start copying its packed words out
-    auto complete = [&](int b) -> int {
-        Pending& p = pending[b];
-        if (!p.live) return GTSC_OK;
+    const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_npoints, true);
+    // Copy-in runs two chunks ahead of the kernels.  On the work stream a chunk's kernels are followed by
+    // its copy-out, which the host can only enqueue once it knows the chunk's size -- hence one host wait
+    // per chunk, during which the copy-in stream has the next two chunks to move.
+    struct Geometry { uint64_t s0, s1, ns, p0, np, slot_total, uniform_slot; const uint64_t* d_pt_off; const uint64_t* d_slot_off; } geo[NSTAGE];
+    bool used[NSTAGE] = {};
+    auto copy_in_chunk = [&](size_t k) -> int {
+        const int b = (int)(k % NSTAGE);
         auto& st = c->stage[b];
-        HIP_TRY(hipStreamSynchronize(st.stream));
-        const uint64_t ns = p.s1 - p.s0;
-        // out_off[s0+1 .. s1] hold chunk-local prefix sums; make them global
-        for (uint64_t i = 1; i <= ns; i++) out_off[p.s0 + i] += base;
-        const uint64_t total = out_off[p.s1] - base;
-        if (base + total > out_capacity_words) overflow = true;
-        else if (total)
-            HIP_TRY(hipMemcpyAsync(out_words + base, st.compact.p, total * sizeof(uint64_t), hipMemcpyDeviceToHost, st.stream));
-        base += total;
-        p.live = false;
-        return GTSC_OK;
-    };
-
-    for (size_t k = 0; k < chunks.size(); k++) {
-        const int b = (int)(k & 1);
-        if (int rc = complete(b)) return rc;  // the chunk that used this stage two steps ago
-        auto& st = c->stage[b];
-        HIP_TRY(hipStreamSynchronize(st.stream));  // its copy-out must be done before the buffers are reused
-        const uint64_t s0 = chunks[k].s0, s1 = chunks[k].s1, ns = s1 - s0;
-        const uint64_t p0 = pt_off ? pt_off[s0] : s0 * uniform_npoints;
-        const uint64_t np = (pt_off ? pt_off[s1] : s1 * uniform_npoints) - p0;
-        uint64_t slot_total, uniform_slot = 0;
-        const uint64_t* d_pt_off = nullptr;
-        const uint64_t* d_slot_off = nullptr;
+        if (used[b]) HIP_TRY(hipEventSynchronize(st.drained));  // the stage's previous chunk has left its buffers
+        used[b] = true;
+        Geometry& g = geo[b];
+        g.s0 = chunks[k].s0; g.s1 = chunks[k].s1; g.ns = g.s1 - g.s0;
+        g.p0 = pt_off ? pt_off[g.s0] : g.s0 * uniform_npoints;
+        g.np = (pt_off ? pt_off[g.s1] : g.s1 * uniform_npoints) - g.p0;
+        g.uniform_slot = 0; g.d_pt_off = nullptr; g.d_slot_off = nullptr;
+        const uint64_t ns = g.ns;
         if (pt_off) {
-            rebased[b].resize(ns + 1);
-            slot_off[b].resize(ns + 1);
-            slot_off[b][0] = 0;
-            for (uint64_t i = 0; i <= ns; i++) rebased[b][i] = pt_off[s0 + i] - p0;
-            for (uint64_t i = 0; i < ns; i++) slot_off[b][i + 1] = slot_off[b][i] + gtsc_max_words(rebased[b][i + 1] - rebased[b][i]);
-            slot_total = slot_off[b][ns];
+            HIP_TRY(st.h_off_a.reserve((ns + 1) * 8));
+            HIP_TRY(st.h_off_b.reserve((ns + 1) * 8));
+            uint64_t* const rebased = st.h_off_a.as<uint64_t>();
+            uint64_t* const slot_off = st.h_off_b.as<uint64_t>();
+            slot_off[0] = 0;
+            for (uint64_t i = 0; i <= ns; i++) rebased[i] = pt_off[g.s0 + i] - g.p0;
+            for (uint64_t i = 0; i < ns; i++) slot_off[i + 1] = slot_off[i] + gtsc_max_words(rebased[i + 1] - rebased[i]);
+            g.slot_total = slot_off[ns];
             HIP_TRY(st.pt_off.reserve((ns + 1) * 8));
             HIP_TRY(st.slot_off.reserve((ns + 1) * 8));
-            HIP_TRY(hipMemcpyAsync(st.pt_off.p, rebased[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
-            HIP_TRY(hipMemcpyAsync(st.slot_off.p, slot_off[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
-            d_pt_off = st.pt_off.as<uint64_t>();
-            d_slot_off = st.slot_off.as<uint64_t>();
+            HIP_TRY(hipMemcpyAsync(st.pt_off.p, rebased, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_in));
+            HIP_TRY(hipMemcpyAsync(st.slot_off.p, slot_off, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_in));
+            g.d_pt_off = st.pt_off.as<uint64_t>();
+            g.d_slot_off = st.slot_off.as<uint64_t>();
         } else {
-            uniform_slot = gtsc_max_words(uniform_npoints);
-            slot_total = uniform_slot * ns;
+            g.uniform_slot = gtsc_max_words(uniform_npoints);
+            g.slot_total = g.uniform_slot * ns;
         }
         HIP_TRY(st.block_ts.reserve(ns * 8));
-        HIP_TRY(st.ts.reserve(np * 8 + 8));
-        HIP_TRY(st.val.reserve(np * 8 + 8));
-        HIP_TRY(st.slots.reserve(slot_total * 8));
-        HIP_TRY(st.compact.reserve(slot_total * 8));
+        HIP_TRY(st.ts.reserve(g.np * 8 + 8));
+        HIP_TRY(st.val.reserve(g.np * 8 + 8));
+        HIP_TRY(st.slots.reserve(g.slot_total * 8));
+        HIP_TRY(st.compact.reserve(g.slot_total * 8));
         HIP_TRY(st.nwords.reserve(ns * 8));
         if (out_nbits) HIP_TRY(st.nbits.reserve(ns * 8));
         HIP_TRY(st.coff.reserve((ns + 1) * 8));
-        HIP_TRY(c->scan_scratch.reserve(scan_scratch_words(CHUNK_SERIES) * 2 * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpyAsync(st.block_ts.p, block_ts + s0, ns * 8, hipMemcpyHostToDevice, st.stream));
-        if (np) {
-            HIP_TRY(hipMemcpyAsync(st.ts.p, ts + p0, np * 8, hipMemcpyHostToDevice, st.stream));
-            HIP_TRY(hipMemcpyAsync(st.val.p, val + p0, np * 8, hipMemcpyHostToDevice, st.stream));
+        HIP_TRY(hipMemcpyAsync(st.block_ts.p, block_ts + g.s0, ns * 8, hipMemcpyHostToDevice, c->copy_in));
+        if (g.np) {
+            HIP_TRY(hipMemcpyAsync(st.ts.p, ts + g.p0, g.np * 8, hipMemcpyHostToDevice, c->copy_in));
+            HIP_TRY(hipMemcpyAsync(st.val.p, val + g.p0, g.np * 8, hipMemcpyHostToDevice, c->copy_in));
         }
-        EncodeArgs a{ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
-                     Layout{d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot},
+        HIP_TRY(hipEventRecord(st.copied_in, c->copy_in));
+        return GTSC_OK;
+    };
+
+    HIP_TRY(c->scan_scratch.reserve(scan_scratch_words(CHUNK_SERIES) * sizeof(uint64_t)));
+    uint64_t base = 0;      // words produced by the chunks completed so far
+    bool overflow = false;
+    for (size_t k = 0; k < chunks.size() && k < 2; k++)
+        if (int rc = copy_in_chunk(k)) return rc;
+    for (size_t k = 0; k < chunks.size(); k++) {
+        if (k + 2 < chunks.size())
+            if (int rc = copy_in_chunk(k + 2)) return rc;
+        const int b = (int)(k % NSTAGE);
+        auto& st = c->stage[b];
+        const Geometry& g = geo[b];
+        HIP_TRY(hipStreamWaitEvent(c->work, st.copied_in, 0));
+        EncodeArgs a{g.ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
+                     Layout{g.d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{g.d_slot_off, g.uniform_slot},
                      st.nwords.as<uint64_t>(), nullptr, c->d_flags_host, out_nbits ? st.nbits.as<uint64_t>() : nullptr,
                      (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, nullptr, c->dfcm_mask, 0u, ~0ull};
-        HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
-        HIP_TRY(launch_encode(a, format, st.stream));
-        if (out_nbits) HIP_TRY(hipMemcpyAsync(out_nbits + s0, st.nbits.p, ns * 8, hipMemcpyDeviceToHost, st.stream));
-        uint64_t* scratch = c->scan_scratch.as<uint64_t>() + (size_t)b * scan_scratch_words(CHUNK_SERIES);
-        HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), ns, st.coff.as<uint64_t>(), scratch, st.stream));
-        HIP_TRY(launch_compact_copy(ns, st.slots.as<uint64_t>(), Layout{d_slot_off, uniform_slot}, st.nwords.as<uint64_t>(),
-                                    st.compact.as<uint64_t>(), st.coff.as<uint64_t>(), st.stream));
-        HIP_TRY(hipMemcpyAsync(out_off + s0 + 1, st.coff.as<uint64_t>() + 1, ns * 8, hipMemcpyDeviceToHost, st.stream));
-        pending[b] = {true, s0, s1};
-        // chunks complete in order: the other stage's chunk is older
-        if (int rc = complete(b ^ 1)) return rc;
+        HIP_TRY(dfcm_prepare(c, 1 + b, g.ns, c->work, &a.dfcm_tables));
+        HIP_TRY(launch_encode(a, format, c->work));
+        HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), g.ns, st.coff.as<uint64_t>(), c->scan_scratch.as<uint64_t>(), c->work));
+        HIP_TRY(launch_compact_copy(g.ns, st.slots.as<uint64_t>(), Layout{g.d_slot_off, g.uniform_slot}, st.nwords.as<uint64_t>(),
+                                    st.compact.as<uint64_t>(), st.coff.as<uint64_t>(), c->work));
+        if (out_nbits) HIP_TRY(hipMemcpyAsync(out_nbits + g.s0, st.nbits.p, g.ns * 8, hipMemcpyDeviceToHost, c->work));
+        HIP_TRY(hipMemcpyAsync(out_off + g.s0 + 1, st.coff.as<uint64_t>() + 1, g.ns * 8, hipMemcpyDeviceToHost, c->work));
+        HIP_TRY(hipEventRecord(st.coded, c->work));
+        HIP_TRY(hipEventSynchronize(st.coded));
+        // out_off[s0+1 .. s1] hold chunk-local prefix sums; make them global
+        for (uint64_t i = 1; i <= g.ns; i++) out_off[g.s0 + i] += base;
+        const uint64_t total = out_off[g.s1] - base;
+        if (base + total > out_capacity_words) overflow = true;
+        else if (total)
+            HIP_TRY(hipMemcpyAsync(out_words + base, st.compact.p, total * sizeof(uint64_t), hipMemcpyDeviceToHost, c->work));
+        HIP_TRY(hipEventRecord(st.drained, c->work));
+        base += total;
     }
-    // at most one chunk is still pending: the last one
-    if (int rc = complete((int)((chunks.size() - 1) & 1))) return rc;
-    for (auto& st : c->stage) HIP_TRY(hipStreamSynchronize(st.stream));
+    HIP_TRY(hipStreamSynchronize(c->work));
     uint32_t flags = 0;
-    if (int rc = read_flags(c, c->stage[0].stream, &flags)) return rc;
+    if (int rc = read_flags(c, c->work, &flags)) return rc;
     if (overflow) return fail(GTSC_ERR_CAPACITY, "out_words holds %llu words, the batch needs %llu",
                               (unsigned long long)out_capacity_words, (unsigned long long)out_off[nseries]);
     if (flags) return fail(GTSC_ERR_HIP, "internal: worst-case slot overflowed (flags 0x%x)", flags);
@@ -570,26 +619,29 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
     DeviceGuard g(c->device);
     if (int rc = ensure_stage_streams(c)) return rc;
 
-    const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_capacity);
-    std::vector<uint64_t> reb_in[2], reb_pt[2];
+    const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_capacity, false);
+    bool used[NSTAGE] = {};
     for (size_t k = 0; k < chunks.size(); k++) {
-        const int b = (int)(k & 1);
+        const int b = (int)(k % NSTAGE);
         auto& st = c->stage[b];
-        HIP_TRY(hipStreamSynchronize(st.stream));
+        if (used[b]) HIP_TRY(hipEventSynchronize(st.drained));  // the stage's previous chunk has left its buffers
+        used[b] = true;
         const uint64_t s0 = chunks[k].s0, s1 = chunks[k].s1, ns = s1 - s0;
         const uint64_t w0 = in_off[s0], nw = in_off[s1] - w0;
         const uint64_t p0 = pt_off ? pt_off[s0] : s0 * uniform_capacity;
         const uint64_t np = (pt_off ? pt_off[s1] : s1 * uniform_capacity) - p0;
-        reb_in[b].resize(ns + 1);
-        for (uint64_t i = 0; i <= ns; i++) reb_in[b][i] = in_off[s0 + i] - w0;
+        HIP_TRY(st.h_off_a.reserve((ns + 1) * 8));
+        uint64_t* const reb_in = st.h_off_a.as<uint64_t>();
+        for (uint64_t i = 0; i <= ns; i++) reb_in[i] = in_off[s0 + i] - w0;
         HIP_TRY(st.slot_off.reserve((ns + 1) * 8));
-        HIP_TRY(hipMemcpyAsync(st.slot_off.p, reb_in[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
+        HIP_TRY(hipMemcpyAsync(st.slot_off.p, reb_in, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_in));
         const uint64_t* d_pt_off = nullptr;
         if (pt_off) {
-            reb_pt[b].resize(ns + 1);
-            for (uint64_t i = 0; i <= ns; i++) reb_pt[b][i] = pt_off[s0 + i] - p0;
+            HIP_TRY(st.h_off_b.reserve((ns + 1) * 8));
+            uint64_t* const reb_pt = st.h_off_b.as<uint64_t>();
+            for (uint64_t i = 0; i <= ns; i++) reb_pt[i] = pt_off[s0 + i] - p0;
             HIP_TRY(st.pt_off.reserve((ns + 1) * 8));
-            HIP_TRY(hipMemcpyAsync(st.pt_off.p, reb_pt[b].data(), (ns + 1) * 8, hipMemcpyHostToDevice, st.stream));
+            HIP_TRY(hipMemcpyAsync(st.pt_off.p, reb_pt, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_in));
             d_pt_off = st.pt_off.as<uint64_t>();
         }
         HIP_TRY(st.compact.reserve(nw * 8 + 8));
@@ -597,24 +649,30 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         HIP_TRY(st.val.reserve(np * 8 + 8));
         HIP_TRY(st.npoints.reserve(ns * 8));
         HIP_TRY(st.status.reserve(ns * 4));
-        if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, st.stream));
+        if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, c->copy_in));
+        HIP_TRY(hipEventRecord(st.copied_in, c->copy_in));
+        HIP_TRY(hipStreamWaitEvent(c->work, st.copied_in, 0));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
                      st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
                      nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u /* the host form knows the density */, nullptr,
-                     ~0ull, nullptr, 0, c->d_long_count + 1 + b};
-        HIP_TRY(dfcm_prepare(c, 1 + b, ns, st.stream, &a.dfcm_tables));
-        HIP_TRY(launch_decode(a, format, st.stream));
+                     ~0ull, nullptr, 0, c->d_long_count + 1};
+        HIP_TRY(dfcm_prepare(c, 1 + b, ns, c->work, &a.dfcm_tables));
+        HIP_TRY(launch_decode(a, format, c->work));
+        HIP_TRY(hipEventRecord(st.coded, c->work));
+        HIP_TRY(hipStreamWaitEvent(c->copy_out, st.coded, 0));
         if (np) {
-            HIP_TRY(hipMemcpyAsync(ts + p0, st.ts.p, np * 8, hipMemcpyDeviceToHost, st.stream));
-            HIP_TRY(hipMemcpyAsync(val + p0, st.val.p, np * 8, hipMemcpyDeviceToHost, st.stream));
+            HIP_TRY(hipMemcpyAsync(ts + p0, st.ts.p, np * 8, hipMemcpyDeviceToHost, c->copy_out));
+            HIP_TRY(hipMemcpyAsync(val + p0, st.val.p, np * 8, hipMemcpyDeviceToHost, c->copy_out));
         }
-        HIP_TRY(hipMemcpyAsync(out_npoints + s0, st.npoints.p, ns * 8, hipMemcpyDeviceToHost, st.stream));
-        if (status) HIP_TRY(hipMemcpyAsync(status + s0, st.status.p, ns * 4, hipMemcpyDeviceToHost, st.stream));
+        HIP_TRY(hipMemcpyAsync(out_npoints + s0, st.npoints.p, ns * 8, hipMemcpyDeviceToHost, c->copy_out));
+        if (status) HIP_TRY(hipMemcpyAsync(status + s0, st.status.p, ns * 4, hipMemcpyDeviceToHost, c->copy_out));
+        HIP_TRY(hipEventRecord(st.drained, c->copy_out));
     }
-    for (auto& st : c->stage) HIP_TRY(hipStreamSynchronize(st.stream));
+    HIP_TRY(hipStreamSynchronize(c->work));
+    HIP_TRY(hipStreamSynchronize(c->copy_out));
     uint32_t flags = 0;
-    if (int rc = read_flags(c, c->stage[0].stream, &flags)) return rc;
+    if (int rc = read_flags(c, c->work, &flags)) return rc;
     if (flags & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", flags);
     if (flags & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series hold more points than their ts/val slot");
     return GTSC_OK;

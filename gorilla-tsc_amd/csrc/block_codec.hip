@@ -17,6 +17,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "codec_device.hpp"
 #include "kernels.hpp"
 #include "wave_util.hpp"
@@ -402,6 +404,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     uint32_t qn = 0;                  // queued points
     uint64_t cur = pos;               // walk position (pos is the committed one, where queue entry 0 starts)
     uint32_t wnb = nbits; int32_t wtr = trail;   // window at the walk position
+    uint32_t stride_pause = 0, poor = 0;
     bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
     bool clean_end = finished;
 
@@ -411,7 +414,10 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
             // Dense streams (a window of 29 bits or more): the positions cur + j * stride, where stride
             // is the length of a point with regular cadence that reuses the window ('0' + '10' +
             // payload) -- as long as every point is of that kind, all 64 candidates are real starts.
-            const bool strided = wnb >= 29;
+            // (a stream whose points rarely have that form -- windows that change all the time -- gets one
+            // point per strided step: after two steps in a row that yielded fewer than four, the next eight are not strided)
+            const bool strided = wnb >= 29 && stride_pause == 0;
+            if (stride_pause) stride_pause--;
             const uint32_t stride = strided ? 3u + wnb : 1u;
             while ((uint64_t)filled * 64 < cur + 64 * (uint64_t)stride + 64 * 4) { GTSC_RING_LAND() }
             wave_sync();
@@ -471,48 +477,64 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                     }
                 }
                 real = found >= 64 ? ~0ull : (1ull << found) - 1ull;
+                // two poor strided steps in a row: the stream is not of the regular kind, leave it for a while
+                poor = found < 4 ? poor + 1 : 0;
+                if (poor >= 2) { stride_pause = 8; poor = 0; }
             } else {
             const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
             uint32_t p = 0;
-            while (p < 64) {
-                const uint64_t here = cur + p;
-                // runs of unchanged points: '00' each
-                const uint64_t rest = span << p;
-                uint32_t zpairs = (rest ? (uint32_t)__builtin_clzll(rest) : 64u - p) >> 1;
-                if (zpairs) {
-                    const uint64_t room = limit > here ? (limit - here - 1) >> 1 : 0;   // points of 2 bits that end before the limit
-                    const uint64_t left = cap - n - qn - found;                        // and fit the capacity
-                    bool cut = false;
-                    if (zpairs > room) { zpairs = (uint32_t)room; cut = true; }
-                    if (zpairs > left) { zpairs = (uint32_t)left; cut = true; }
+            uint32_t packed = len | (vtype << 8);            // what a hop needs to know about a candidate
+            // Far from the end of the image and of the capacity, with a window defined and no end marker
+            // among the candidates, a hop has nothing to check.
+            const bool safe = wnb != 0 && !any_lane(eos) && cur + 64 + 128 < limit && n + qn + 64 < cap;
+            auto walk = [&](auto safe_tag) {
+                constexpr bool SAFE = decltype(safe_tag)::value;
+                while (p < 64) {
+                    const uint64_t here = cur + p;
+                    // runs of unchanged points: '00' each
+                    const uint64_t rest = span << p;
+                    uint32_t zpairs = (rest ? (uint32_t)__builtin_clzll(rest) : 64u - p) >> 1;
                     if (zpairs) {
-                        const uint64_t m = (0x5555555555555555ull >> (64 - 2 * zpairs)) << p;   // bits p, p+2, ...
-                        real |= m;
-                        found += zpairs;
-                        p += 2 * zpairs;
+                        bool cut = false;
+                        if (!SAFE) {
+                            const uint64_t room = limit > here ? (limit - here - 1) >> 1 : 0;   // points of 2 bits that end before the limit
+                            const uint64_t left = cap - n - qn - found;                        // and fit the capacity
+                            if (zpairs > room) { zpairs = (uint32_t)room; cut = true; }
+                            if (zpairs > left) { zpairs = (uint32_t)left; cut = true; }
+                        }
+                        if (zpairs) {
+                            const uint64_t m = (0x5555555555555555ull >> (64 - 2 * zpairs)) << p;   // bits p, p+2, ...
+                            real |= m;
+                            found += zpairs;
+                            p += 2 * zpairs;
+                        }
+                        if (cut) { stop = true; break; }
+                        continue;
                     }
-                    if (cut) { stop = true; break; }
-                    continue;
+                    const uint32_t pk = read_lane(packed, p);
+                    const uint32_t l = pk & 255u, ty = pk >> 8;
+                    if (!SAFE) {
+                        if (read_lane((uint32_t)eos, p)) {
+                            stop = true;
+                            clean_end = here + 36 < limit;   // the marker itself must not run off the image
+                            break;
+                        }
+                        if ((ty == 1 && wnb == 0) || here + l >= limit || n + qn + found >= cap) { stop = true; break; }
+                    }
+                    real |= 1ull << p;
+                    found++;
+                    if (ty == 2) {
+                        // a new window from here on: candidates that reuse the window change length
+                        wnb = read_lane(own_sig, p);
+                        wtr = (int32_t)read_lane((uint32_t)own_trail, p);
+                        len = fixed + (vtype == 1 ? wnb : 0u);
+                        packed = len | (vtype << 8);
+                        if (lane > p) { lane_nb = wnb; lane_tr = wtr; }
+                    }
+                    p += l;
                 }
-                const uint32_t l = read_lane(len, p);
-                const uint32_t ty = read_lane(vtype, p);
-                if (read_lane((uint32_t)eos, p)) {
-                    stop = true;
-                    clean_end = here + 36 < limit;   // the marker itself must not run off the image
-                    break;
-                }
-                if ((ty == 1 && wnb == 0) || here + l >= limit || n + qn + found >= cap) { stop = true; break; }
-                real |= 1ull << p;
-                found++;
-                if (ty == 2) {
-                    // a new window from here on: candidates that reuse the window change length
-                    wnb = read_lane(own_sig, p);
-                    wtr = (int32_t)read_lane((uint32_t)own_trail, p);
-                    len = fixed + (vtype == 1 ? wnb : 0u);
-                    if (lane > p) { lane_nb = wnb; lane_tr = wtr; }
-                }
-                p += l;
-            }
+            };
+            if (safe) walk(std::true_type{}); else walk(std::false_type{});
             adv = p;
             }
             // queue the real starts
@@ -545,8 +567,15 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
             const uint64_t x = have ? q.bits << ((uint32_t)q.trail & 63u) : 0ull;
             const uint64_t dd = have ? (uint64_t)q.dd : 0ull;
             // timestamps: deltas are the running sum of the delta-of-deltas, timestamps of the deltas
-            const uint64_t delta = (uint64_t)stored_delta + wave_inclusive_scan64<false>(dd);
-            const uint64_t ts = stored_ts + wave_inclusive_scan64<false>(have ? delta : 0ull);
+            uint64_t delta, ts;
+            if (!any_lane(dd != 0)) {
+                // regular cadence throughout: no sums needed
+                delta = (uint64_t)stored_delta;
+                ts = stored_ts + (uint64_t)(lane + 1) * delta;
+            } else {
+                delta = (uint64_t)stored_delta + wave_inclusive_scan64<false>(dd);
+                ts = stored_ts + wave_inclusive_scan64<false>(have ? delta : 0ull);
+            }
             const uint64_t v = val ^ wave_inclusive_scan64<true>(x);
             // a timestamp of exactly zero turns the next point into a "first" one: not this path's business
             if (any_lane(have && ts == 0)) {

@@ -228,8 +228,8 @@ int gtsc_compact_device_noalloc(gtsc_ctx *ctx, uint64_t nseries,
 /*
  * Host-memory forms: every pointer is host memory and the call returns when
  * the results are in the caller's arrays.  The batch is cut into chunks of
- * whole series; each chunk is copied in, coded and copied out on one of two
- * alternating streams so that copies overlap kernels.  Host arrays obtained
+ * whole series; each chunk is copied in on one stream, coded and copied out on one of two
+ * more that take turns, so that copies overlap kernels and each other.  Host arrays obtained
  * from gtsc_host_alloc() are page-locked and move by DMA at PCIe rate; other
  * memory works but is staged by the HIP runtime.
  *
