@@ -3,17 +3,103 @@
 // series read from a text file, and writes what it got for the caller to compare.
 //
 //   mirror_test <in.txt> <out.txt>
+//   mirror_test shapes <outdir>     the shapes of three of the reference's tests (see shapes())
 // in.txt : "<nseries>" then per series "<format> <block_ts> <npoints>" and npoints lines
 //          "<ts> <value bits as hex>"
 // out.txt: per series "<nwords>" + words (hex), then "<npairs>" + pairs "<ts> <hex>"
 #include <cinttypes>
 #include <cstdio>
 #include <memory>
+#include <string>
 
 #include "gorilla.hpp"
 
+// The value of point i in the large shapes: the reference's tests use i * Math.random(); here a
+// multiplicative hash stands in for the random number, so that the checker can make the same series.
+static double shape_value(uint32_t i) { return (double)i * ((double)(uint32_t)(i * 2654435761u) / 4294967296.0); }
+
+static void write_file(const std::string& path, const void* p, size_t bytes)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f || std::fwrite(p, 1, bytes, f) != bytes) throw std::runtime_error("cannot write " + path);
+    std::fclose(f);
+}
+
+// Three shapes of the reference's test suite (T/ = src/test/java/fi/iki/yak/ts/compression/gorilla/):
+//   testCopyFlush                          T/EncodeGorillaTest.java:483-500  getLongArray() before close() is decodable
+//   testEncodeLargeAmountOfDataOldBuffer   T/EncodeGorillaTest.java:420-462  100,000 points through ByteBufferBitOutput/Input
+//   testDifferentialFCM                    T/EncodeGorillaTest.java:550-589  100,000 points with DifferentialFCM(1024) on both sides
+// Each checks here what the reference's test asserts, and leaves images and decoded values in
+// <outdir> for the caller to compare with the oracle.
+static int shapes(const std::string& dir)
+{
+    const int64_t B = 1500400800000LL;
+    {   // ---- testCopyFlush
+        gorilla::LongArrayOutput out;
+        gorilla::GorillaCompressor c(B, out);
+        c.addValue(B + 1, 1.0);
+        c.addValue(B + 2, 1.0);
+        const std::vector<int64_t> snap = out.getLongArray();   // no close()
+        gorilla::LongArrayInput in(snap);
+        gorilla::GorillaDecompressor d(in);
+        const gorilla::Pair* p = d.readPair();
+        if (!p || p->getTimestamp() != B + 1 || p->getDoubleValue() != 1.0) throw std::runtime_error("copyflush: first pair");
+        p = d.readPair();
+        if (!p || p->getTimestamp() != B + 2 || p->getDoubleValue() != 1.0) throw std::runtime_error("copyflush: second pair");
+        write_file(dir + "/copyflush_words.bin", snap.data(), snap.size() * 8);
+        // the block can still be added to and closed afterwards
+        c.addValue(B + 3, 2.0);
+        c.close();
+        const std::vector<int64_t> whole = out.getLongArray();
+        write_file(dir + "/copyflush_closed_words.bin", whole.data(), whole.size() * 8);
+    }
+    const uint32_t N = 100000;
+    {   // ---- testEncodeLargeAmountOfDataOldBuffer
+        gorilla::ByteBufferBitOutput out;
+        gorilla::GorillaCompressor c(B, out);
+        for (uint32_t i = 0; i < N; i++) c.addValue(B + 60 * (int64_t)(i + 1), shape_value(i));
+        c.close();
+        const std::vector<uint8_t> bytes = out.getByteBuffer();
+        write_file(dir + "/oldbuffer_bytes.bin", bytes.data(), bytes.size());
+        gorilla::ByteBufferBitInput in(bytes);
+        gorilla::GorillaDecompressor d(in);
+        for (uint32_t i = 0; i < N; i++) {
+            const gorilla::Pair* p = d.readPair();
+            if (!p || p->getTimestamp() != B + 60 * (int64_t)(i + 1) || p->getDoubleValue() != shape_value(i))
+                throw std::runtime_error("oldbuffer: pair " + std::to_string(i));
+        }
+        if (d.readPair()) throw std::runtime_error("oldbuffer: no end of stream");
+    }
+    {   // ---- testDifferentialFCM
+        gorilla::LongArrayOutput out;
+        gorilla::DifferentialFCM enc_pred(1024), dec_pred(1024);
+        gorilla::GorillaCompressor c(B, out, enc_pred);
+        for (uint32_t i = 0; i < N; i++) c.addValue(B + 60 * (int64_t)(i + 1), shape_value(i));
+        c.close();
+        const std::vector<int64_t> words = out.getLongArray();
+        write_file(dir + "/dfcm_words.bin", words.data(), words.size() * 8);
+        gorilla::LongArrayInput in(words);
+        gorilla::GorillaDecompressor d(in, dec_pred);
+        std::vector<int64_t> vals;
+        while (const gorilla::Pair* p = d.readPair()) {
+            if (p->getTimestamp() != B + 60 * (int64_t)(vals.size() + 1)) throw std::runtime_error("dfcm: timestamp");
+            vals.push_back(p->getLongValue());
+        }
+        if (vals.size() != N) throw std::runtime_error("dfcm: pair count");
+        write_file(dir + "/dfcm_values.bin", vals.data(), vals.size() * 8);
+        bool rejected = false;
+        try { gorilla::DifferentialFCM bad(0); } catch (const std::invalid_argument&) { rejected = true; }
+        if (!rejected) throw std::runtime_error("dfcm: size 0 accepted");
+    }
+    std::printf("shapes ok\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 3 && std::string(argv[1]) == "shapes") {
+        try { return shapes(argv[2]); } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc != 3) { std::fprintf(stderr, "usage: %s in out\n", argv[0]); return 2; }
     FILE* in = std::fopen(argv[1], "r");
     FILE* out = std::fopen(argv[2], "w");
@@ -46,7 +132,7 @@ int main(int argc, char** argv)
         }
         batch.flush();
         for (size_t s = 0; s < S; s++) {
-            const std::vector<int64_t>& w = outs[s]->getLongArray();
+            const std::vector<int64_t> w = outs[s]->getLongArray();
             std::fprintf(out, "%zu\n", w.size());
             for (int64_t x : w) std::fprintf(out, "%016" PRIx64 "\n", (uint64_t)x);
             gorilla::LongArrayInput input(w);
@@ -65,7 +151,8 @@ int main(int argc, char** argv)
         c1.addValue(1500400801000LL, 1.5);
         c1.addValue(1500400802000LL, 2.5);
         c1.close();
-        std::vector<int64_t> cut(o1.getLongArray().begin(), o1.getLongArray().begin() + 2);
+        const std::vector<int64_t> whole = o1.getLongArray();
+        std::vector<int64_t> cut(whole.begin(), whole.begin() + 2);
         gorilla::LongArrayInput in_cut(cut);
         gorilla::GorillaDecompressor dcut(in_cut);
         int got = 0; bool threw = false;

@@ -21,6 +21,8 @@ public final class Gtsc {
     public static final int OK = 0, ERR_ARG = -1, ERR_CAPACITY = -2, ERR_HIP = -3, ERR_STREAM = -4;
     public static final int FMT_V2 = 0, FMT_V1 = 1;
     public static final int ST_OVERFLOW = 1, ST_TRUNCATED = 2, ST_MALFORMED = 4;
+    public static final int PRED_LAST = 0, PRED_DFCM = 1;
+    public static final int ENC_NO_CLOSE = 1;
 
     private static final Linker LINKER = Linker.nativeLinker();
     private static final SymbolLookup LIB =
@@ -41,6 +43,12 @@ public final class Gtsc {
      *                      out_words, out_capacity_words, out_off) */
     static final MethodHandle ENCODE_HOST = h("gtsc_encode_host", FunctionDescriptor.of(JAVA_INT,
             ADDRESS, JAVA_INT, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, JAVA_LONG, ADDRESS));
+    /* int gtsc_encode_host_ex(ctx, format, options, nseries, block_ts, ts, val, pt_off, uniform_npoints,
+     *                         out_words, out_capacity_words, out_off, out_nbits) */
+    static final MethodHandle ENCODE_HOST_EX = h("gtsc_encode_host_ex", FunctionDescriptor.of(JAVA_INT,
+            ADDRESS, JAVA_INT, JAVA_INT, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS));
+    /* int gtsc_set_predictor(ctx, predictor, table_size) */
+    static final MethodHandle SET_PREDICTOR = h("gtsc_set_predictor", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT));
     /* int gtsc_decode_host(ctx, format, nseries, words, in_off, ts, val, pt_off, uniform_capacity,
      *                      out_npoints, status) */
     static final MethodHandle DECODE_HOST = h("gtsc_decode_host", FunctionDescriptor.of(JAVA_INT,

@@ -1,9 +1,10 @@
 package fi.iki.yak.ts.compression.gorilla.gpu;
 
-public class LongArrayInput {
+public class LongArrayInput extends BitInput {
     private final long[] array;
 
     public LongArrayInput(long[] array) { this.array = array; }
 
-    long[] array() { return array; }
+    @Override
+    long[] words() { return array; }
 }

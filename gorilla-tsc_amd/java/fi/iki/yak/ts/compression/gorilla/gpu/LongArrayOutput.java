@@ -1,14 +1,11 @@
 package fi.iki.yak.ts.compression.gorilla.gpu;
 
-/** The block image, as LongArrayOutput.getLongArray() of the reference returns it. */
-public class LongArrayOutput {
-    private long[] image = new long[0];
-
+/** The block image, as LongArrayOutput.getLongArray() of the reference returns it (G/LongArrayOutput.java:141-145). */
+public class LongArrayOutput extends BitOutput {
     public LongArrayOutput() { }
 
     public LongArrayOutput(int initialSize) { }
 
-    void set(long[] words) { image = words; }
-
-    public long[] getLongArray() { return image.clone(); }
+    /** After close() the whole block; before it the words completed so far plus the current partial word. */
+    public long[] getLongArray() { return stream().clone(); }
 }

@@ -66,3 +66,34 @@ def test_mirror_matches_oracle(tmp_path, golden):
                                                                            np.array([1.5, 2.5]).view(np.uint64), O.V2))
     assert tail[4] == "threw" and tail[5] == "1"
     assert tail[7:9] == ["5", "-3"]
+
+
+@pytest.mark.gpu
+def test_mirror_reference_test_shapes(tmp_path):
+    """testCopyFlush, testEncodeLargeAmountOfDataOldBuffer and testDifferentialFCM of the reference
+    (T/EncodeGorillaTest.java:483-500, 420-462, 550-589) driven through the C++ mirror on the GPU: the driver
+    asserts what the Java tests assert; here its images and decoded values are compared with the oracle's."""
+    r = subprocess.run([BIN, "shapes", str(tmp_path)], capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "shapes ok" in r.stdout, r.stdout + r.stderr
+    B = 1500400800000
+    # testCopyFlush: the snapshot before close(), then the closed block
+    e = O.Encoder(B, O.V2)
+    e.add(B + 1, np.float64(1.0).view(np.uint64)); e.add(B + 2, np.float64(1.0).view(np.uint64))
+    assert np.array_equal(np.fromfile(tmp_path / "copyflush_words.bin", dtype=np.uint64), e.words())
+    e.add(B + 3, np.float64(2.0).view(np.uint64)); e.close()
+    assert np.array_equal(np.fromfile(tmp_path / "copyflush_closed_words.bin", dtype=np.uint64), e.words())
+    # the large shapes: value i = i * hash(i) / 2^32, as the driver computes it
+    N = 100000
+    i = np.arange(N, dtype=np.uint64)
+    h = (i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    val = (i.astype(np.float64) * (h.astype(np.float64) / 4294967296.0)).view(np.uint64)
+    ts = B + 60 * np.arange(1, N + 1, dtype=np.int64)
+    e = O.Encoder(B, O.V2)
+    for t, v in zip(ts.tolist(), val.tolist()):
+        e.add(t, v)
+    e.close()
+    assert (tmp_path / "oldbuffer_bytes.bin").read_bytes() == e.bytes()   # the ByteBufferBitOutput image
+    ref = O.encode_block(B, ts, val, O.V2, dfcm_size=1024)
+    assert np.array_equal(np.fromfile(tmp_path / "dfcm_words.bin", dtype=np.uint64), ref)
+    rts, rval, rc = O.decode_block(ref, O.V2, dfcm_size=1024)
+    assert rc == O.END and np.array_equal(np.fromfile(tmp_path / "dfcm_values.bin", dtype=np.uint64), rval)
