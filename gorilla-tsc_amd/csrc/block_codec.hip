@@ -404,21 +404,19 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     uint32_t qn = 0;                  // queued points
     uint64_t cur = pos;               // walk position (pos is the committed one, where queue entry 0 starts)
     uint32_t wnb = nbits; int32_t wtr = trail;   // window at the walk position
-    uint32_t stride_pause = 0, poor = 0;
+    uint32_t last_len = 0;            // length of the last point the walk passed
     bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
     bool clean_end = finished;
 
     while (!(stop && qn == 0)) {
         if (!stop) {
             // ---- one step: 64 candidate starts.  Sparse streams: the 64 bit positions from cur on.
-            // Dense streams (a window of 29 bits or more): the positions cur + j * stride, where stride
-            // is the length of a point with regular cadence that reuses the window ('0' + '10' +
-            // payload) -- as long as every point is of that kind, all 64 candidates are real starts.
-            // (a stream whose points rarely have that form -- windows that change all the time -- gets one
-            // point per strided step: after two steps in a row that yielded fewer than four, the next eight are not strided)
-            const bool strided = wnb >= 29 && stride_pause == 0;
-            if (stride_pause) stride_pause--;
-            const uint32_t stride = strided ? 3u + wnb : 1u;
+            // Dense streams (the last point took 32 bits or more): the positions cur + j * stride, where
+            // stride is the length of the last point -- while the points that follow have the same form
+            // (same timestamp bucket, same window), all 64 candidates are real starts.
+            // (The 64 bit positions would hold two such points at most.)
+            const bool strided = last_len >= 32;
+            const uint32_t stride = strided ? last_len : 1u;
             while ((uint64_t)filled * 64 < cur + 64 * (uint64_t)stride + 64 * 4) { GTSC_RING_LAND() }
             wave_sync();
             const uint64_t b = cur + (uint64_t)lane * stride;
@@ -453,7 +451,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
             uint64_t adv = 0;                                // bits the walk moves on by
             if (strided) {
                 // the chain holds while every candidate has the predicted length and opens no window
-                const bool ok = !eos && vtype != 2 && len == stride && b + len < limit && n + qn + lane < cap;
+                const bool ok = !eos && vtype != 2 && !(vtype == 1 && wnb == 0) && len == stride && b + len < limit && n + qn + lane < cap;
                 const uint64_t bad = lanes(!ok);
                 const uint32_t js = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
                 found = js;
@@ -465,11 +463,12 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                     if (read_lane((uint32_t)eos, js)) {
                         stop = true;
                         clean_end = here + 36 < limit;
-                    } else if (here + l >= limit || n + qn + js >= cap) {
-                        stop = true;
+                    } else if ((read_lane(vtype, js) == 1 && wnb == 0) || here + l >= limit || n + qn + js >= cap) {
+                        stop = true;   // a window reused before any was defined, the end of the image, or of the capacity
                     } else {
                         found = js + 1;
                         adv += l;
+                        last_len = l;
                         if (read_lane(vtype, js) == 2) {
                             wnb = read_lane(own_sig, js);
                             wtr = (int32_t)read_lane((uint32_t)own_trail, js);
@@ -477,9 +476,6 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                     }
                 }
                 real = found >= 64 ? ~0ull : (1ull << found) - 1ull;
-                // two poor strided steps in a row: the stream is not of the regular kind, leave it for a while
-                poor = found < 4 ? poor + 1 : 0;
-                if (poor >= 2) { stride_pause = 8; poor = 0; }
             } else {
             const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
             uint32_t p = 0;
@@ -507,6 +503,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                             real |= m;
                             found += zpairs;
                             p += 2 * zpairs;
+                            last_len = 2;
                         }
                         if (cut) { stop = true; break; }
                         continue;
@@ -532,6 +529,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                         if (lane > p) { lane_nb = wnb; lane_tr = wtr; }
                     }
                     p += l;
+                    last_len = l;
                 }
             };
             if (safe) walk(std::true_type{}); else walk(std::false_type{});
