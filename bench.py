@@ -107,17 +107,115 @@ def cpu_baseline(block, ts, val, P, sample_series, threads):
 
 
 def pmc_traffic(workload, S, P, kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE with the gfx950
-    correction + WRITE_SIZE) that tools/profile.sh collected for this same workload, or None.
-    Counters cannot be read from inside the timed process, so the figure is carried in a file."""
+    """(HBM bytes per launch of `kernel`, where the figure comes from): the rocprofv3 PMC passes (FETCH_SIZE
+    with the gfx950 correction + WRITE_SIZE) that tools/profile.sh collected for this same workload, or
+    (None, None).  Counters cannot be read from inside the timed process, so the figure is carried in a file."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return None, None
     if (t.get("workload"), t.get("series"), t.get("points")) != (workload, S, P):
-        return None
-    return t.get(kernel + "_bytes")
+        return None, None
+    return t.get(kernel + "_bytes"), "profiles/traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of %s)" % t.get("taken", "an earlier run")
+
+
+EXTRA_WORKLOADS = [
+    # (key, workload, series, points): the dense and long-block configurations, reported beside the headline
+    ("gauge_drift_1Mx120", "gauge_drift", 1_000_000, 120),
+    ("random_walk_262144x7200", "random_walk", 262_144, 7200),
+    ("adversarial_65536x7200", "adversarial", 65_536, 7200),
+    ("gauge_16668x7200", "gauge", 16_668, 7200),
+]
+
+
+def other_workloads(measure, ctx):
+    """The configurations the headline does not cover, each compress + decompress device-resident like the
+    headline (5 timed steps after 3), plus one 7,200-point block alone and the host-to-host rates."""
+    out = {}
+    for key, wl, S, P in EXTRA_WORKLOADS:
+        try:
+            m = measure(wl, S, P, 5, 3, 0x5EED0100)
+        except Exception as e:  # an extra must not take the headline down with it
+            out[key] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+            continue
+        slow = max(m["enc_ms"], m["dec_ms"])
+        out[key] = {
+            "compress_GBps": round(m["raw_bytes"] / m["enc_ms"] / 1e6, 1), "decompress_GBps": round(m["raw_bytes"] / m["dec_ms"] / 1e6, 1),
+            "raw_only_frac_of_hbm_peak": {"compress": round(m["raw_bytes"] / m["enc_ms"] / 1e6 / HBM_PEAK_GBPS, 4),
+                                          "decompress": round(m["raw_bytes"] / m["dec_ms"] / 1e6 / HBM_PEAK_GBPS, 4)},
+            "roofline_frac": round(m["algo_bytes"] / slow / 1e6 / HBM_PEAK_GBPS, 4),
+            "encode_ms": round(m["enc_ms"], 4), "decode_ms": round(m["dec_ms"], 4),
+            "compressed_bits_per_point": round(64.0 * m["total_words"] / (S * P), 3),
+        }
+        torch.cuda.empty_cache()
+    try:
+        out["one_block_7200_random_walk"] = one_block(ctx)
+    except Exception as e:
+        out["one_block_7200_random_walk"] = {"error": repr(e)[:200]}
+    return out
+
+
+def one_block(ctx):
+    """One series, one 2-hour block at 1 s cadence (7,200 random-walk doubles): the reference's own use.
+    GPU: wall time of a device-resident compress and decompress call incl. launch and sync; CPU: the C
+    oracle, one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as O
+    b = synth.random_walk(S=1, P=7200)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
+    d_block, d_ts, d_val = d(b.block_ts), d(b.ts), d(b.val)
+    slot = G.max_words(7200)
+    d_out = torch.zeros(slot, dtype=torch.int64, device="cuda")
+    d_nw = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d_ts2, d_val2 = torch.zeros_like(d_ts), torch.zeros_like(d_val)
+    d_np = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    te = td = 1e9
+    for _ in range(20):
+        t0 = time.perf_counter()
+        ctx.encode_device(d_block, d_ts, d_val, d_out, d_nw, uniform_npoints=7200, uniform_slot_words=slot)
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.decode_device(d_out, d_ts2, d_val2, d_np, 1, uniform_slot_words=slot, in_nwords=d_nw, uniform_capacity=7200)
+        ctx.sync()
+        t2 = time.perf_counter()
+        te, td = min(te, t1 - t0), min(td, t2 - t1)
+    assert torch.equal(d_ts2, d_ts) and torch.equal(d_val2, d_val)
+    ce = cd = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        w, off, nw, _ = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, nthreads=1)
+        t1 = time.perf_counter()
+        O.decode_batch(w, off, nw, b.pt_off, nthreads=1)
+        t2 = time.perf_counter()
+        ce, cd = min(ce, t1 - t0), min(cd, t2 - t1)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64)[: int(nw[0])], w[: int(nw[0])])
+    return {"gpu_compress_us": round(te * 1e6, 1), "gpu_decompress_us": round(td * 1e6, 1),
+            "cpu_port_one_thread_compress_us": round(ce * 1e6, 1), "cpu_port_one_thread_decompress_us": round(cd * 1e6, 1),
+            "note": "GPU figures are whole calls (launch + sync), best of 20; CPU best of 5"}
+
+
+def host_to_host():
+    """gtsc_encode_host / gtsc_decode_host on pinned host buffers, PCIe copies included (never the headline value):
+    2^26 points of uniform gauges and of skewed lengths (10 to 100,000 points, constant / counter / random-walk
+    series).  Run by tools/host_bench.py in a child process of its own: the pipeline's three streams plus the
+    context's are what the runtime's four hardware queues carry side by side, and this process holds torch's
+    streams as well."""
+    import subprocess
+    res = {}
+    for kind in ("gauge", "skewed"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_bench.py"), kind, "26"], capture_output=True, text=True,
+                           timeout=300)
+        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not line:
+            res[kind] = {"error": (r.stderr or r.stdout)[-200:]}
+            continue
+        j = json.loads(line[-1])
+        res[kind] = {"series": j["series"], "points": j["points"], "compress_GBps": j["encode_host_GBps"],
+                     "decompress_GBps": j["decode_host_GBps"], "compressed_MB": j["compressed_MB"]}
+    return res
 
 
 def main():
@@ -134,6 +232,8 @@ def main():
     ap.add_argument("--slot-words", type=int, default=0, help="words per output slot (default: the worst case for --points)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other workloads (dense streams, long blocks, one block, "
+                    "host to host) that the default single-GPU run reports under other_workloads")
     ap.add_argument("--no-verify", action="store_true", help="skip the round-trip check (kernel experiments only)")
     ap.add_argument("--val-phase", type=int, default=0, help="start the value array this many 8-byte words into its allocation "
                     "(diagnostic: an odd number puts it on the other 16-byte phase than the timestamps)")
@@ -143,6 +243,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    default_variant = args.format == "v2" and not args.val_phase and not args.slot_words
+    extras = (world == 1 and not args.no_extras and default_variant
+              and (args.workload, args.series, args.points) == ("gauge", 1_000_000, 120))
+    # The host-to-host figures come from child processes that run before this process touches the GPU: two
+    # processes with GPU queues of their own get in each other's way (the copy-out rate halves).
+    h2h = None
+    if extras:
+        try:
+            h2h = host_to_host()
+        except Exception as e:
+            h2h = {"error": repr(e)[:200]}
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -162,76 +273,83 @@ def main():
     red_device = device if args.backend == "nccl" else None  # where the timing reduction's tensor lives
 
     S, P = args.series, args.points
-    block, ts, val = make_workload(args.workload, S, P, device, 0x5EED0002 + rank)
-    if args.val_phase:
-        big = torch.empty(val.numel() + args.val_phase, dtype=val.dtype, device=device)
-        big[args.val_phase:].copy_(val)
-        val = big[args.val_phase:]
-    slot = args.slot_words or G.max_words(P)
-    out = torch.zeros(S * slot, dtype=torch.int64, device=device)
-    nw = torch.zeros(S, dtype=torch.int64, device=device)
-    ts2 = torch.zeros_like(ts)
-    val2 = torch.zeros_like(val)
-    npts = torch.zeros(S, dtype=torch.int64, device=device)
-
     ctx = G.Context(dev_index)
     stream = torch.cuda.Stream(device=device)
     ctx.set_stream(stream.cuda_stream)
-
     fmt = G.FMT_V2 if args.format == "v2" else G.FMT_V1
 
-    def encode():
-        ctx.encode_device(block, ts, val, out, nw, uniform_npoints=P, uniform_slot_words=slot, fmt=fmt)
+    def measure(workload, S, P, steps, warmup, seed, timed_by_host=False, keep_inputs=False):
+        """Compress + decompress `steps` times after `warmup` untimed steps; HIP-event time per kernel
+        (events on the stream the library launches on).  Returns a dict of what was measured."""
+        block, ts, val = make_workload(workload, S, P, device, seed)
+        if args.val_phase:
+            big = torch.empty(val.numel() + args.val_phase, dtype=val.dtype, device=device)
+            big[args.val_phase:].copy_(val)
+            val = big[args.val_phase:]
+        slot = args.slot_words or G.max_words(P)
+        out = torch.zeros(S * slot, dtype=torch.int64, device=device)
+        nw = torch.zeros(S, dtype=torch.int64, device=device)
+        ts2 = torch.zeros_like(ts)
+        val2 = torch.zeros_like(val)
+        npts = torch.zeros(S, dtype=torch.int64, device=device)
 
-    def decode():
-        ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P, fmt=fmt)
+        def encode():
+            ctx.encode_device(block, ts, val, out, nw, uniform_npoints=P, uniform_slot_words=slot, fmt=fmt)
 
-    torch.cuda.synchronize()
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            encode()
-            decode()
-    try:
-        ctx.sync()
-    except G.GtscError:
+        def decode():
+            ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P, fmt=fmt)
+
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for _ in range(warmup):
+                encode()
+                decode()
+        try:
+            ctx.sync()
+        except G.GtscError:
+            if not args.no_verify:
+                raise
+        # parity guard on the very buffers that get timed
         if not args.no_verify:
-            raise
-    # parity guard on the very buffers that get timed
-    if not args.no_verify:
-        assert torch.equal(ts2, ts) and torch.equal(val2, val) and bool((npts == P).all()), "round trip failed"
-    total_words = int(nw.sum())
+            assert torch.equal(ts2, ts) and torch.equal(val2, val) and bool((npts == P).all()), "round trip failed"
+        total_words = int(nw.sum())
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        if timed_by_host and dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for k in range(steps):
+                ev[k][0].record(stream)
+                encode()
+                ev[k][1].record(stream)
+                decode()
+                ev[k][2].record(stream)
+        try:
+            ctx.sync()
+        except G.GtscError:
+            if not args.no_verify:
+                raise
+        torch.cuda.synchronize()
+        if timed_by_host and dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        raw = 16.0 * S * P
+        algo = raw + 8.0 * total_words + 16.0 * S  # raw points + compressed words + per-series block_ts and length
+        r = {"elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "raw_bytes": raw, "algo_bytes": algo, "total_words": total_words}
+        if keep_inputs:
+            r["inputs"] = (block, ts, val)
+        return r
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        for k in range(args.steps):
-            ev[k][0].record(stream)
-            encode()
-            ev[k][1].record(stream)
-            decode()
-            ev[k][2].record(stream)
-    try:
-        ctx.sync()
-    except G.GtscError:
-        if not args.no_verify:
-            raise
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dist, red_device)
-
-    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    raw_bytes = 16.0 * S * P
-    # algorithmic bytes of one launch: raw points + compressed words + per-series block_ts and length
-    algo_bytes = raw_bytes + 8.0 * total_words + 16.0 * S
+    m = measure(args.workload, S, P, args.steps, args.warmup, 0x5EED0002 + rank, timed_by_host=True, keep_inputs=True)
+    block, ts, val = m.pop("inputs")
+    elapsed = shard.max_over_ranks(m["elapsed"], dist, red_device)
+    enc_ms, dec_ms, raw_bytes, algo_bytes, total_words = m["enc_ms"], m["dec_ms"], m["raw_bytes"], m["algo_bytes"], m["total_words"]
     dom, dom_ms = ("encode", enc_ms) if enc_ms >= dec_ms else ("decode", dec_ms)
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = pmc_traffic(args.workload, S, P, dom)
+    traffic, traffic_source = pmc_traffic(args.workload, S, P, dom) if default_variant else (None, None)
 
     result = {
         "metric": "device-resident Gorilla compress/decompress GB/s of raw (ts,double) points",
@@ -260,7 +378,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(dom_ms, 4),
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
         },
@@ -268,6 +386,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)
         result["cpu_baseline"] = cpu_baseline(block, ts, val, P, args.cpu_sample_series, threads)
+    if extras:
+        del block, ts, val
+        torch.cuda.empty_cache()
+        result["other_workloads"] = other_workloads(measure, ctx)
+        result["other_workloads"]["host_to_host"] = h2h
     if rank == 0:
         print(json.dumps(result), flush=True)
     ctx.close()
