@@ -73,3 +73,28 @@ def test_world2_gloo_cpu(tmp_path):
 def test_world2_gloo_gpu(tmp_path):
     """Same, each rank through the HIP library on the one GPU of the box (gloo for the control plane)."""
     _run_world("gpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_bench_command_with_two_ranks(tmp_path):
+    """The multi-GPU benchmark command itself, as the driver launches it (torch.distributed.run, one rank per
+    GPU), rehearsed with two ranks on the one GPU of the box: gloo carries the barrier and the MAX of the
+    timing instead of RCCL, everything else is the code that runs on 8 GPUs."""
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--series", "20000", "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints, once
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["unit"] == "GB/s" and j["value"] > 0 and j["higher_is_better"] is True
+    assert j["config"]["series_per_gpu"] == 20000 and j["config"]["points_per_series"] == 120
+    # whole-job value: both ranks' points over the slower rank's time
+    assert abs(j["value"] - 2 * 2 * 16.0 * 20000 * 120 * 2 / (j["ms_per_step"] * 2 * 1e-3) / 1e9) / j["value"] < 0.02
+    for key in ("roofline", "raw_only_frac_of_hbm_peak", "compress_GBps_per_gpu", "decompress_GBps_per_gpu"):
+        assert key in j
+    assert "cpu_baseline" not in j and "other_workloads" not in j   # single-GPU extras only
