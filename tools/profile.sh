@@ -6,13 +6,13 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 run() { # name, rocprof flags...
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; return 1; }
 }
 # the kernel trace runs the benchmark's own default step counts, so that its averages are the bench line's
-SHORT_ARGS=$ARGS; ARGS="--no-cpu-baseline $*"
+SHORT_ARGS=$ARGS; ARGS="--no-cpu-baseline --no-extras $*"
 run trace --kernel-trace --stats || exit 1
 ARGS=$SHORT_ARGS
 run pmc_sq1 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU || exit 1
