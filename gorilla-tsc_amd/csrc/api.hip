@@ -103,6 +103,7 @@ struct gtsc_ctx {
     uint64_t* d_long_count = nullptr;
     uint64_t* noalloc_scratch = nullptr;  // this device's copy of the library's static scratch array
     bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
+    int forced_ring = 0;            // gtsc_set_decode_ring: 0 = by density, 8 or 16 = always that form
     DeviceBuf scan_scratch;
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
     int predictor = GTSC_PRED_LAST;
@@ -247,6 +248,15 @@ int gtsc_set_predictor(gtsc_ctx* c, int predictor, int table_size)
     return GTSC_OK;
 }
 
+int gtsc_set_decode_ring(gtsc_ctx* c, int ring_words)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (ring_words != 0 && ring_words != 8 && ring_words != 16) return fail(GTSC_ERR_ARG, "ring_words must be 0, 8 or 16");
+    c->forced_ring = ring_words;
+    if (ring_words) c->deep_ring = ring_words == 16;
+    return GTSC_OK;
+}
+
 int gtsc_set_stream(gtsc_ctx* c, void* hip_stream)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -264,7 +274,7 @@ int gtsc_sync(gtsc_ctx* c)
     const uint32_t f = *c->h_flags;
     {   // how dense were the streams decoded since the last sync: the next decodes use the ring that suits them
         const uint64_t* counts = reinterpret_cast<const uint64_t*>(c->h_flags) + 1;
-        if (counts[1]) c->deep_ring = counts[0] * 64 > counts[1] * DENSE_BITS_PER_POINT;
+        if (counts[1] && !c->forced_ring) c->deep_ring = counts[0] * 64 > counts[1] * DENSE_BITS_PER_POINT;
     }
     if (f & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", f);
     if (f & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series overflowed their output slot");
@@ -655,7 +665,8 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
                      st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
-                     nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u /* the host form knows the density */, nullptr,
+                     (c->forced_ring ? c->forced_ring == 16 : nw * 64 > np * DENSE_BITS_PER_POINT) ? 1u : 0u /* the host form knows the density */,
+                     nullptr,
                      ~0ull, nullptr, 0, c->d_long_count + 1};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, c->work, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, c->work));

@@ -22,7 +22,7 @@ SYMBOLS = (
     "gtsc_version", "gtsc_last_error", "gtsc_max_words", "gtsc_create", "gtsc_destroy", "gtsc_set_stream",
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
     "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
-    "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex", "gtsc_compact_device_noalloc",
+    "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex", "gtsc_compact_device_noalloc", "gtsc_set_decode_ring",
 )
 NOALLOC_MAX_SERIES = 8_000_000
 PRED_LAST, PRED_DFCM = 0, 1
@@ -67,6 +67,8 @@ def lib():
     L.gtsc_set_stream.argtypes = [vp, vp]
     L.gtsc_set_predictor.restype = i32
     L.gtsc_set_predictor.argtypes = [vp, i32, i32]
+    L.gtsc_set_decode_ring.restype = i32
+    L.gtsc_set_decode_ring.argtypes = [vp, i32]
     L.gtsc_sync.restype = i32
     L.gtsc_sync.argtypes = [vp]
     L.gtsc_encode_device.restype = i32
@@ -149,6 +151,9 @@ class Context:
 
     def set_predictor(self, predictor, table_size=0):
         _check(lib().gtsc_set_predictor(self._h, int(predictor), int(table_size)))
+
+    def set_decode_ring(self, ring_words):
+        _check(lib().gtsc_set_decode_ring(self._h, int(ring_words)))
 
     def sync(self):
         try:

@@ -92,6 +92,19 @@ int gtsc_destroy(gtsc_ctx *ctx);
 #define GTSC_PRED_DFCM 1
 int gtsc_set_predictor(gtsc_ctx *ctx, int predictor, int table_size);
 
+/*
+ * Which form of the lane-per-series decompressor gtsc_decode_device uses.  It exists with input rings
+ * of 8 words per series (fastest on streams of a few bits per point) and of 16 words (fastest on
+ * streams of tens of bits per point); results are identical, only the speed differs.
+ * ring_words = 0 (the default): chosen from what the context decoded before its last gtsc_sync()
+ * -- above 40 compressed bits per point the 16-word form -- so the first decode after
+ * gtsc_create() uses 8, and a change of density takes effect one sync later.
+ * ring_words = 8 or 16: always that form (a benchmark, or a caller that knows its data).
+ * gtsc_decode_host knows each chunk's density beforehand and needs no hint.
+ * No reference counterpart.
+ */
+int gtsc_set_decode_ring(gtsc_ctx *ctx, int ring_words);
+
 /* Enqueue on a caller-owned hipStream_t instead of the context's own
  * (NULL restores the context's stream). */
 int gtsc_set_stream(gtsc_ctx *ctx, void *hip_stream);

@@ -588,6 +588,24 @@ def test_lane_per_series_kernels_in_their_own_process():
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+def test_decode_ring_choice_is_explicit(ctx):
+    """gtsc_set_decode_ring pins the form of the lane-per-series decompressor (8- or 16-word input rings):
+    same points, counts and status either way, on sparse and on dense streams; 0 gives the choice back."""
+    try:
+        for b in (synth.gauge_integer(S=3000, P=120), synth.adversarial(S=200, P=700)):
+            out, off, nw, _, _ = check_encode_against_oracle(ctx, b, G.FMT_V2, O.V2, uniform=True)
+            got = []
+            for ring in (8, 16, 0):
+                ctx.set_decode_ring(ring)
+                ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, G.FMT_V2, uniform_cap=b.uniform_npoints())
+                assert rc == 0 and not st.any()
+                assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+        with pytest.raises(G.GtscError):
+            ctx.set_decode_ring(12)
+    finally:
+        ctx.set_decode_ring(0)
+
+
 def test_wave_per_block_kernels_forced_in_their_own_process():
     """The wave-per-block kernels normally take blocks of 1,024 points and more (the decompressor only in
     batches of few such blocks).  GTSC_LONG_POINTS=0 sends every block to them, whatever its length, and
