@@ -1184,6 +1184,27 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
 // The wave-per-block decompressor finds the starts of a block's points speculatively, which costs several
 // times the instructions per point of a lane-per-series wave: it pays while the long blocks of a batch are
 // too few to fill the machine with lanes (GTSC_LONG_DECODE_MAX overrides the count).
+// Dense streams decode faster from 16-word rings, but a compute unit holds 7 such waves against 8 with
+// 8-word rings.  When a batch is only a few rounds of waves (long series: a wave lives for
+// milliseconds), what counts is how the waves fill the rounds: 4,096 waves are two full rounds of 8 per
+// unit but two and a third of 7.  The model: a full round costs 1 (0.92 with 16-word rings, measured on
+// dense streams), the last, partly filled one 0.55 + 0.45 x its fill (fewer waves per unit run faster).
+static bool deep_ring_pays(uint32_t waves)
+{
+    static const uint32_t units = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return (uint32_t)n;
+    }();
+    if (waves > 4u * 8u * units) return true;  // many rounds: the tail is small change
+    auto cost = [waves](uint32_t slots, double round) {
+        const uint32_t rem = waves % slots;
+        return ((double)(waves / slots) + (rem ? 0.55 + 0.45 * (double)rem / (double)slots : 0.0)) * round;
+    };
+    return cost(7u * units, 0.92) <= cost(8u * units, 1.0);
+}
+
 static uint64_t long_decode_max()
 {
     static const uint64_t v = [] {
@@ -1227,7 +1248,8 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
         static const int forced = [] { const char* e = getenv("GTSC_RING"); return e ? atoi(e) : 0; }();  // tests: 8 or 16
-        const bool deep = forced ? forced == 16 : a.deep_ring != 0;
+        bool deep = forced ? forced == 16 : a.deep_ring != 0;
+        if (!forced && a.deep_ring == 1) deep = deep_ring_pays(blocks);
         if (format == FMT_V2) {
             if (deep) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 16>), dim3(blocks), dim3(64), 0, stream, g);
             else      hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 8>), dim3(blocks), dim3(64), 0, stream, g);
