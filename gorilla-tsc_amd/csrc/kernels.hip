@@ -217,6 +217,12 @@ constexpr uint32_t RING_WORDS = 16;
 constexpr uint32_t RING_BLOCK = 8;
 constexpr uint32_t RING_TRIGGER = RING_WORDS - 4;
 
+#ifndef GTSC_LAND_LOW
+#define GTSC_LAND_LOW 5u
+#endif
+#ifndef GTSC_LAND_AGE
+#define GTSC_LAND_AGE 5u
+#endif
 #ifndef GTSC_LDS_PAD
 #define GTSC_LDS_PAD 0
 #endif
@@ -576,7 +582,8 @@ template <int FMT, uint32_t RING>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void decode_tiled_kernel(DecodeArgs a)
 {
     constexpr uint32_t IN_RING_WORDS = RING;          // ring capacity per row (8 or 16)
-    constexpr uint32_t IN_RING_LOW = RING - 2;        // top up while unread words <= this (2 free slots)
+    constexpr uint32_t TOPUP = RING == 16 ? 4 : 2;    // words per top-up (one or two 16-byte loads of the lane)
+    constexpr uint32_t IN_RING_LOW = RING - TOPUP;    // top up while unread words <= this (room for one top-up)
     constexpr uint32_t IN_RING_ROW_BYTES = (IN_RING_WORDS + 3) * 8;  // + mirror of slots 0 and 1 (a 3-word window never wraps) + bank padding
     constexpr uint32_t OFF_TS = TILE_BYTES;
     constexpr uint32_t OFF_RING = OFF_TS + DEC_TS_TILE_BYTES;
@@ -678,23 +685,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     // ---- top-up state: the lane's load in flight between two checks
     uint32_t pend = 0;  // 1: a top-up of this lane is in flight (an integer: see lanes())
     uint32_t dense = 0;  // wave-uniform: > 0 after a lane outran its top-ups: the rings are then looked after at every point for a while
-    U4 tq;  // defined whenever pend is set
-    uint32_t tback = 0;
+    U4 tq, tq2;  // defined whenever pend is set (tq2: the second half of a four-word top-up)
+    uint32_t tback = 0, tback2 = 0;
     // The source of the next top-up is worked out when the ring's end moves, not when the load is
     // made: computed on the spot, the address would go through registers that the compiler takes
     // from the previous top-up's, and writing those makes it wait for everything in flight --
     // the chunk's stores included (one counter, in order).
     const uint64_t* tsrc = image;
+    const uint64_t* tsrc2 = image;
+    // A four-word top-up is two loads made together.  Where the slot ends before the second pair of
+    // words, the second load fetches the first pair again (no branch of its own: the compiler would
+    // wait for both loads where its arms join); what it puts into the ring lies past the image.
 #define GTSC_TOPUP_NEXT()                                                                      \
     {                                                                                          \
         tback = (filled + 1 < ssz) ? 0u : 1u;                                                  \
         tsrc = image + (filled - tback);                                                       \
+        if constexpr (TOPUP == 4) {                                                            \
+            tback2 = (filled + 3 < ssz) ? 0u : 1u;                                             \
+            tsrc2 = (filled + 2 < ssz) ? image + (filled + 2 - tback2) : tsrc;                 \
+        }                                                                                      \
     }
     GTSC_TOPUP_NEXT()
 #define GTSC_TOPUP_LAND()                                                                      \
     {                                                                                          \
         GTSC_RING_STORE(tq, tback, filled)                                                     \
-        filled += 2;                                                                           \
+        if constexpr (TOPUP == 4) GTSC_RING_STORE(tq2, tback2, filled + 2)                     \
+        filled += TOPUP;                                                                       \
         guard = filled >= nw ? nw : filled - 2;                                                \
         limit = (filled >= nw || !active) ? IN_NEVER : (filled > IN_RING_LOW ? filled - IN_RING_LOW : 0u);                   \
         pend = 0;                                                                              \
@@ -703,6 +719,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #define GTSC_TOPUP_ISSUE() /* lanes with widx >= limit: filled < nw <= ssz */                  \
     {                                                                                          \
         tq = load16(tsrc);                                                                     \
+        if constexpr (TOPUP == 4) tq2 = load16(tsrc2);                                         \
         pend = 1;                                                                              \
         limit = IN_NEVER; /* nothing more until this one has landed */                         \
     }
@@ -728,22 +745,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #else
 #define GTSC_TILE_WRITE(T_, P_, X_) *reinterpret_cast<T_*>(P_) = (T_)(X_);
 #endif
-#if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
+    // The three-word window of a lane's next point is read from its ring as soon as the position is
+    // known -- at the end of the point before -- so that the LDS round trip runs under the rest of
+    // that point (votes, tile writes, top-up checks) instead of at the head of the next one.  A point
+    // that commits wholesale has its successor's window inside the ring already (new position <
+    // guard); top-ups that land in between write other slots.
     uint64_t w0, w1, w2;
-    { const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); w0 = w[0]; w1 = w[1]; w2 = w[2]; }
+#define GTSC_WINDOW_READ()                                                                     \
+    {                                                                                          \
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); \
+        w0 = w[0]; w1 = w[1]; w2 = w[2];                                                       \
+    }
+    GTSC_WINDOW_READ()
+#if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
+#undef GTSC_WINDOW_READ
 #define GTSC_WINDOW_READ() asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
 #define GTSC_FORCE_FAST true
 #else
-#define GTSC_WINDOW_READ()                                                                     \
-        const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); \
-        const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
 #define GTSC_FORCE_FAST false
 #endif
 // One point of every lane.  Finished lanes ride along on the wholesale path (their rows are
 // bounded at flush time), so a ragged wave keeps using it.
 #define GTSC_POINT(KK)                                                                         \
     {                                                                                          \
-        GTSC_WINDOW_READ()                                                                     \
         bool done = false;                                                                     \
         if (slow_m == 0) {                                                                     \
             const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);                     \
@@ -767,6 +791,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                                      lanes((uint32_t)(t.stored_ts >> 32) != ts_ref)) & active_m; \
             if (GTSC_FORCE_FAST || rare_m == 0) {                                              \
                 d = t;                                                                         \
+                GTSC_WINDOW_READ()                                                             \
                 GTSC_TILE_WRITE(uint32_t, tile_ts + adt + (KK) * 4, d.stored_ts)               \
                 GTSC_TILE_WRITE(uint64_t, tile_val + ad + (KK) * 8, d.val)                     \
                 n++;                                                                           \
@@ -811,6 +836,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             }                                                                                  \
             slow_m = lanes(skip != 0 || d.stored_ts == 0) & lanes(active);                     \
             active_m = lanes(active);                                                          \
+            GTSC_WINDOW_READ()                                                                 \
         }                                                                                      \
     }
     for (uint32_t c = 0; active_m != 0; c++) {
@@ -835,7 +861,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 // pend counts the checks a top-up has been in flight: it lands when its lane is down to
                 // five unread words or the load is five checks old (all that are in flight land with it;
                 // measured: landing earlier waits more often, landing later starves the densest lanes)
-                const bool due = pend != 0 && (filled - d.widx <= 5u || pend >= 5u);
+                const bool due = pend != 0 && (filled - d.widx <= GTSC_LAND_LOW || pend >= GTSC_LAND_AGE);
                 if (any_lane(due)) { if (pend) GTSC_TOPUP_LAND() }
                 else pend += pend ? 1u : 0u;
             }
@@ -1187,7 +1213,7 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
 // Dense streams decode faster from 16-word rings, but a compute unit holds 7 such waves against 8 with
 // 8-word rings.  When a batch is only a few rounds of waves (long series: a wave lives for
 // milliseconds), what counts is how the waves fill the rounds: 4,096 waves are two full rounds of 8 per
-// unit but two and a third of 7.  The model: a full round costs 1 (0.92 with 16-word rings, measured on
+// unit but two and a third of 7.  The model: a full round costs 1 (0.72 with 16-word rings, measured on
 // dense streams), the last, partly filled one 0.55 + 0.45 x its fill (fewer waves per unit run faster).
 static bool deep_ring_pays(uint32_t waves)
 {
@@ -1202,7 +1228,7 @@ static bool deep_ring_pays(uint32_t waves)
         const uint32_t rem = waves % slots;
         return ((double)(waves / slots) + (rem ? 0.55 + 0.45 * (double)rem / (double)slots : 0.0)) * round;
     };
-    return cost(7u * units, 0.92) <= cost(8u * units, 1.0);
+    return cost(7u * units, 0.72) <= cost(8u * units, 1.0);
 }
 
 static uint64_t long_decode_max()
