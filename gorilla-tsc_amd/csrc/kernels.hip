@@ -734,11 +734,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t n0 = 0;                   // n when the chunk began
     uint32_t dmask = 0;                // slots of this chunk whose timestamps the lane stored itself
 #ifdef GTSC_STAMP
-    uint64_t tk_comp = 0, tk_flush = 0, tk_prev = __builtin_amdgcn_s_memtime();
+    uint64_t tk_comp = 0, tk_flush = 0, tk_land = 0, tk_prev = __builtin_amdgcn_s_memtime();
     const uint64_t tk_pro = tk_prev - tk_entry;
 #define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
+#define GTSC_LAND_STAMP() { __builtin_amdgcn_sched_barrier(0); const uint64_t t0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tk_land += __builtin_amdgcn_s_memtime() - t0_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define GTSC_TICK(acc_)
+#define GTSC_LAND_STAMP()
 #endif
 #if GTSC_ABLATE == 5 || GTSC_ABLATE == 7
 #define GTSC_TILE_WRITE(T_, P_, X_) asm volatile("" ::"v"(X_));
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 // five unread words or the load is five checks old (all that are in flight land with it;
                 // measured: landing earlier waits more often, landing later starves the densest lanes)
                 const bool due = pend != 0 && (filled - d.widx <= GTSC_LAND_LOW || pend >= GTSC_LAND_AGE);
-                if (any_lane(due)) { if (pend) GTSC_TOPUP_LAND() }
+                if (any_lane(due)) { GTSC_LAND_STAMP() if (pend) GTSC_TOPUP_LAND() }
                 else pend += pend ? 1u : 0u;
             }
             const bool low = d.widx >= limit;
@@ -971,7 +973,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     }
 #ifdef GTSC_STAMP
     wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
-    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; }
+    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; a.out_npoints[s + 7] = tk_land; }
 #endif
 }
 

@@ -144,7 +144,11 @@ class Context:
             lib().gtsc_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:  # interpreter shutdown: the module's globals are gone already
+            pass
 
     def set_stream(self, hip_stream):
         _check(lib().gtsc_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))

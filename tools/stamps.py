@@ -33,7 +33,7 @@ torch.cuda.synchronize()
 for _ in range(2):
     ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P)
 ctx.sync()
-d = npts.view(-1, 64)[:, 1:7].cpu().numpy().astype(np.float64)
+d = npts.view(-1, 64)[:, 1:8].cpu().numpy().astype(np.float64)
 tot = d[:, :3].sum(1).mean()
-for i, n in enumerate(["decode compute", "decode flush", "decode prologue", "  entry->fill loads issued", "  issued->ring written", "  entry->kernel arguments there"]):
+for i, n in enumerate(["decode compute", "decode flush", "decode prologue", "  entry->fill loads issued", "  issued->ring written", "  entry->kernel arguments there", "  of compute: waiting at landings (16-word ring)"]):
     print("%-28s mean %9.0f cycles/wave  (%.1f%%)" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot))
