@@ -359,7 +359,7 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
-                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, 6u, c->forced_ring == 16 ? 2u : (c->deep_ring ? 1u : 0u),
+                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, c->forced_ring == 16 ? 2u : (c->deep_ring ? 1u : 0u),
                  reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
@@ -664,7 +664,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         HIP_TRY(hipStreamWaitEvent(c->work, st.copied_in, 0));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
-                     st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u, 6u,
+                     st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
                      (c->forced_ring ? (c->forced_ring == 16 ? 2u : 0u) : (nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u)) /* the host form knows the density */,
                      nullptr,
                      ~0ull, nullptr, 0, c->d_long_count + 1};

@@ -405,18 +405,22 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     uint64_t cur = pos;               // walk position (pos is the committed one, where queue entry 0 starts)
     uint32_t wnb = nbits; int32_t wtr = trail;   // window at the walk position
     uint32_t last_len = 0;            // length of the last point the walk passed
+    uint32_t last_found = 0;          // points the last step found, if it went by strides
     bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
     bool clean_end = finished;
 
     while (!(stop && qn == 0)) {
         if (!stop) {
             // ---- one step: 64 candidate starts.  Sparse streams: the 64 bit positions from cur on.
-            // Dense streams (the last point took 32 bits or more): the positions cur + j * stride, where
-            // stride is the length of the last point -- while the points that follow have the same form
-            // (same timestamp bucket, same window), all 64 candidates are real starts.
+            // Dense streams (windows of 29 bits or more): the positions cur + j * stride -- while the
+            // points that follow have the predicted form, all 64 candidates are real starts.
             // (The 64 bit positions would hold two such points at most.)
-            const bool strided = last_len >= 32;
-            const uint32_t stride = strided ? last_len : 1u;
+            // The stride is that of a point with an unchanged delta and a reused value window
+            // ('0', '10', payload): what a dense stream mostly consists of.  A step that ends at a point
+            // of another kind (an unchanged value, a new window, another timestamp bucket) takes that
+            // point along and the next step predicts again -- as long as such steps find points at all.
+            const bool strided = wnb != 0 && wnb >= 29 && (last_len >= 32 || last_found >= 2);
+            const uint32_t stride = strided ? 3u + wnb : 1u;
             while ((uint64_t)filled * 64 < cur + 64 * (uint64_t)stride + 64 * 4) { GTSC_RING_LAND() }
             wave_sync();
             const uint64_t b = cur + (uint64_t)lane * stride;
@@ -476,7 +480,9 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                     }
                 }
                 real = found >= 64 ? ~0ull : (1ull << found) - 1ull;
+                last_found = found;
             } else {
+            last_found = 0;
             const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
             uint32_t p = 0;
             uint32_t packed = len | (vtype << 8);            // what a hop needs to know about a candidate

@@ -599,14 +599,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint64_t tk_p1 = 0, tk_p2 = 0;
 #endif
     const uint32_t lane = threadIdx.x;
-    // A batch of fewer waves than the chip has SIMDs is spread over more of them: a wave then takes
-    // only its first 2^lanes_log2 lanes' worth of series (8, 16 or 32 rows of the tiles; a wave's
-    // instructions cost the same however many lanes take part).
-    const uint32_t wave_rows = 1u << a.lanes_log2;
-    const uint64_t s = a.lanes_log2 == 6 ? series_of_lane(blockIdx.x, lane, a.group_shift)
-                                         : ((uint64_t)blockIdx.x << a.lanes_log2) + lane;
-    const bool valid = lane < wave_rows && s < a.nseries && !left_to_block_kernel(a, s);
-    const uint64_t row_lanes = wave_rows == 64 ? ~0ull : (1ull << wave_rows) - 1ull;  // the lanes whose rows exist
+    const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
+    const bool valid = s < a.nseries && !left_to_block_kernel(a, s);
 #ifdef GTSC_STAMP
     uint64_t tk_pk;
     {
@@ -892,36 +886,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         wave_sync();
         const uint32_t j0 = 2 * piece;
         const uint32_t v0 = c * DCH + j0;
-        const uint32_t passes = wave_rows / ROWS_PER_PASS;  // the rows beyond wave_rows hold nothing
         U4 ri[PASSES];
 #pragma unroll
-        for (uint32_t i = 0; i < PASSES; i++)
-            if (i < passes) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
-        if ((lanes(info == DEC_ROW_FULL) | ~row_lanes) == ~0ull) {
+        for (uint32_t i = 0; i < PASSES; i++) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
+        if (all_lanes(info == DEC_ROW_FULL)) {
             // every row has all 16 slots of this chunk: read everything, then store everything
             uint2 qt[PASSES];
             U4 qv[PASSES];
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
-                if (i < passes) {
-                    const uint32_t r = lrow + i * ROWS_PER_PASS;
-                    qt[i] = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
-                    qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
-                }
+                const uint32_t r = lrow + i * ROWS_PER_PASS;
+                qt[i] = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
+                qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
             }
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
-                if (i < passes) {
-                    const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
-                    const U4 t = {qt[i].x, ri[i].w, qt[i].y, ri[i].w};
+                const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
+                const U4 t = {qt[i].x, ri[i].w, qt[i].y, ri[i].w};
 #if GTSC_ABLATE == 4
-                    asm volatile("" ::"v"(t), "v"(qv[i]), "v"(idx));
+                asm volatile("" ::"v"(t), "v"(qv[i]), "v"(idx));
 #else
-                    // whole aligned lines that nothing reads again soon: streaming stores
-                    __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
-                    __builtin_nontemporal_store(qv[i], reinterpret_cast<U4a8*>(a.val + idx));
+                // whole aligned lines that nothing reads again soon: streaming stores
+                __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
+                __builtin_nontemporal_store(qv[i], reinterpret_cast<U4a8*>(a.val + idx));
 #endif
-                }
             }
         } else {
             // ragged chunk (a block's first or last one, or directly stored timestamps): the same
@@ -930,29 +918,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             U4 qv[PASSES];
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
-                if (i < passes) {
-                    const uint32_t r = lrow + i * ROWS_PER_PASS;
-                    qt[i] = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
-                    qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
-                }
+                const uint32_t r = lrow + i * ROWS_PER_PASS;
+                qt[i] = *reinterpret_cast<const uint2*>(tile_ts + dec_ts_addr(r, j0));
+                qv[i] = *reinterpret_cast<const U4*>(tile_val + tile_addr(r, piece));
             }
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
-                if (i < passes) {
-                    const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
-                    const uint32_t rlo = ri[i].z & 255u, rhi = (ri[i].z >> 8) & 255u, direct = ri[i].z >> 16;
-                    const bool ok0 = j0 >= rlo && j0 < rhi;
-                    const bool ok1 = j0 + 1 >= rlo && j0 + 1 < rhi;
-                    const bool t0 = ok0 && !((direct >> j0) & 1u), t1 = ok1 && !((direct >> (j0 + 1)) & 1u);
-                    if (ok0 & ok1 & t0 & t1) {
-                        store16(a.ts + idx, U4{qt[i].x, ri[i].w, qt[i].y, ri[i].w});
-                        store16(a.val + idx, qv[i]);
-                    } else if (ok0 | ok1) {
-                        if (t0) a.ts[idx] = (int64_t)(((uint64_t)ri[i].w << 32) | qt[i].x);
-                        if (t1) a.ts[idx + 1] = (int64_t)(((uint64_t)ri[i].w << 32) | qt[i].y);
-                        if (ok0) a.val[idx] = lo64(qv[i]);
-                        if (ok1) a.val[idx + 1] = hi64(qv[i]);
-                    }
+                const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
+                const uint32_t rlo = ri[i].z & 255u, rhi = (ri[i].z >> 8) & 255u, direct = ri[i].z >> 16;
+                const bool ok0 = j0 >= rlo && j0 < rhi;
+                const bool ok1 = j0 + 1 >= rlo && j0 + 1 < rhi;
+                const bool t0 = ok0 && !((direct >> j0) & 1u), t1 = ok1 && !((direct >> (j0 + 1)) & 1u);
+                if (ok0 & ok1 & t0 & t1) {
+                    store16(a.ts + idx, U4{qt[i].x, ri[i].w, qt[i].y, ri[i].w});
+                    store16(a.val + idx, qv[i]);
+                } else if (ok0 | ok1) {
+                    if (t0) a.ts[idx] = (int64_t)(((uint64_t)ri[i].w << 32) | qt[i].x);
+                    if (t1) a.ts[idx + 1] = (int64_t)(((uint64_t)ri[i].w << 32) | qt[i].y);
+                    if (ok0) a.val[idx] = lo64(qv[i]);
+                    if (ok1) a.val[idx + 1] = hi64(qv[i]);
                 }
             }
         }
@@ -1233,7 +1217,7 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
 // milliseconds), what counts is how the waves fill the rounds: 4,096 waves are two full rounds of 8 per
 // unit but two and a third of 7.  The model: a full round costs 1 (0.72 with 16-word rings, measured on
 // dense streams), the last, partly filled one 0.55 + 0.45 x its fill (fewer waves per unit run faster).
-static uint32_t compute_units()
+static bool deep_ring_pays(uint32_t waves)
 {
     static const uint32_t units = [] {
         int dev = 0, n = 0;
@@ -1241,11 +1225,6 @@ static uint32_t compute_units()
             n = 256;
         return (uint32_t)n;
     }();
-    return units;
-}
-static bool deep_ring_pays(uint32_t waves)
-{
-    const uint32_t units = compute_units();
     if (waves > 4u * 8u * units) return true;  // many rounds: the tail is small change
     auto cost = [waves](uint32_t slots, double round) {
         const uint32_t rem = waves % slots;
@@ -1254,11 +1233,16 @@ static bool deep_ring_pays(uint32_t waves)
     return cost(7u * units, 0.72) <= cost(8u * units, 1.0);
 }
 
+// Up to how many long blocks a batch is decoded by the wave-per-block kernel.  That kernel's time grows
+// with the number of blocks (0.10-0.28 us per 7,200-point block with all units busy, by kind of
+// stream), the lane-per-series kernel's does not until every SIMD has a wave (it is the time one lane
+// needs for its series, 0.4 us per 1,000 points): 12,288 is where the slowest kind of stream
+// (drifting gauges) breaks even; sparse gauges would at 20,000, random walks at 32,000.
 static uint64_t long_decode_max()
 {
     static const uint64_t v = [] {
         const char* e = getenv("GTSC_LONG_DECODE_MAX");
-        return e ? strtoull(e, nullptr, 10) : 4096ull;
+        return e ? strtoull(e, nullptr, 10) : 12288ull;
     }();
     return v;
 }
@@ -1295,16 +1279,7 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
     } else {
         DecodeArgs g = a;
         g.group_shift = group_shift_of(a.pts);
-        g.lanes_log2 = 6;
-        uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
-        // fewer waves than SIMDs: narrower waves, down to 8 series each, until every SIMD has one
-        static const int lanes_forced = [] { const char* e = getenv("GTSC_DECODE_LANES_LOG2"); return e ? atoi(e) : 0; }();  // tests: 3..6
-        if (g.group_shift == 0) {
-            const uint64_t simds = 4ull * compute_units();
-            while (g.lanes_log2 > 3 && ((a.nseries + (1ull << g.lanes_log2) - 1) >> g.lanes_log2) < simds) g.lanes_log2--;
-            if (lanes_forced >= 3 && lanes_forced <= 6) g.lanes_log2 = (uint32_t)lanes_forced;
-            blocks = (uint32_t)((a.nseries + (1ull << g.lanes_log2) - 1) >> g.lanes_log2);
-        }
+        const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
         static const int forced = [] { const char* e = getenv("GTSC_RING"); return e ? atoi(e) : 0; }();  // tests: 8 or 16
         bool deep = forced ? forced == 16 : a.deep_ring != 0;
         if (!forced && a.deep_ring == 1) deep = deep_ring_pays(blocks);

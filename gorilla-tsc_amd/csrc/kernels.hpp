@@ -43,7 +43,6 @@ struct DecodeArgs {
     int64_t* dfcm_tables;     // as in EncodeArgs
     uint32_t dfcm_mask;
     uint32_t group_shift;     // as in EncodeArgs
-    uint32_t lanes_log2;      // set by the launcher (tiled kernel): a wave takes 2^lanes_log2 series (6 unless the batch has fewer waves than the chip has SIMDs)
     uint32_t deep_ring;       // the tiled kernel's input rings: 0 = 8 words; 1 = the streams are dense, 16 words unless the batch's waves fill the units better with 8; 2 = 16 words
     uint64_t* stats;          // may be null: [0] += words read, [1] += points stored
     // Series whose capacity is at least long_threshold points are decoded by the wave-per-block kernel and left
