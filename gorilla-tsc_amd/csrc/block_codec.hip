@@ -360,13 +360,14 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     if (nw64 > ssz64) nw64 = ssz64;                     // an image cannot be longer than its slot
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
     const uint64_t p0 = a.pts.begin(s);
-    const uint64_t cap = a.pts.size(s);
+    const uint64_t cap64 = a.pts.size(s);
+    const uint32_t cap = cap64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)cap64;   // as in the lane-per-series kernels
     const uint64_t limit = (uint64_t)nw * 64;           // a field must end before this bit (G/LongArrayInput.java:48-52)
 
     // ---- state at the last point handed to the output ("committed"): where the serial decoder takes over
     uint64_t pos = 0;                 // bit position of the next unread bit
-    uint64_t n = 0;                   // points decoded
-    int64_t block_ts = 0, stored_delta = 0;
+    uint32_t n = 0;                   // points decoded
+    int64_t stored_delta = 0;         // (the block timestamp is word 0 of the image whenever it is needed again)
     uint64_t stored_ts = 0, val = 0;
     uint32_t nbits = 0;               // value window: significant bits (0: none yet) and trailing zeros
     int32_t trail = 0;
@@ -386,14 +387,13 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
         wave_sync();
         // header and first point (G/GorillaDecompressor.java:27-35,62-72): nw >= 4, so neither runs off the image
         const uint64_t w0 = lds.ring[0], w1 = lds.ring[1], w2 = lds.ring[2];
-        block_ts = (int64_t)w0;
         const uint32_t d = (uint32_t)(w1 >> 37);
         if (d == 0x7FFFFFFu) {
             finished = true;                             // empty block
         } else {
             val = (w1 << 27) | (w2 >> 37);
             stored_delta = (int64_t)d;
-            stored_ts = (uint64_t)block_ts + d;
+            stored_ts = w0 + d;
             pos = 64 + 91;
             n = 1;
             if (cap == 0 || stored_ts == 0) { serial = true; pos = 64; n = 0; stored_ts = 0; stored_delta = 0; val = 0; }
@@ -406,21 +406,27 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     uint32_t wnb = nbits; int32_t wtr = trail;   // window at the walk position
     uint32_t last_len = 0;            // length of the last point the walk passed
     uint32_t last_found = 0;          // points the last step found, if it went by strides
+    uint32_t hold = 0;                // steps for which sparse windows stay with bit positions
     bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
     bool clean_end = finished;
 
     while (!(stop && qn == 0)) {
         if (!stop) {
             // ---- one step: 64 candidate starts.  Sparse streams: the 64 bit positions from cur on.
-            // Dense streams (windows of 29 bits or more): the positions cur + j * stride -- while the
-            // points that follow have the predicted form, all 64 candidates are real starts.
-            // (The 64 bit positions would hold two such points at most.)
+            // Streams of equal-sized points: the positions cur + j * stride -- while the points that
+            // follow have the predicted form, all 64 candidates are real starts.
             // The stride is that of a point with an unchanged delta and a reused value window
             // ('0', '10', payload): what a dense stream mostly consists of.  A step that ends at a point
             // of another kind (an unchanged value, a new window, another timestamp bucket) takes that
             // point along and the next step predicts again -- as long as such steps find points at all.
-            const bool strided = wnb != 0 && wnb >= 29 && (last_len >= 32 || last_found >= 2);
-            const uint32_t stride = strided ? 3u + wnb : 1u;
+            // Windows under 29 bits: 64 bit positions hold several points, so strides are only taken
+            // while they find more than that (a counter's stream -- '10' and a payload of equal size at
+            // every point -- goes 64 points a step; one with unchanged values mixed in does not).
+            const uint32_t pstride = 3u + wnb;   // (found * pstride > 64: more points than 64 bit positions hold)
+            const bool strided = wnb == 0   ? false
+                                 : wnb >= 29 ? (last_len >= 32 || last_found >= 2)
+                                             : (hold == 0 && (last_len == pstride || last_found * pstride > 64u));
+            const uint32_t stride = strided ? pstride : 1u;
             while ((uint64_t)filled * 64 < cur + 64 * (uint64_t)stride + 64 * 4) { GTSC_RING_LAND() }
             wave_sync();
             const uint64_t b = cur + (uint64_t)lane * stride;
@@ -481,8 +487,10 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                 }
                 real = found >= 64 ? ~0ull : (1ull << found) - 1ull;
                 last_found = found;
+                if (pstride < 32u && found * pstride <= 64u) hold = 4;   // not worth it here: bit positions for the next steps
             } else {
             last_found = 0;
+            hold -= hold ? 1u : 0u;
             const uint64_t span = read_lane(hi, 0);          // the 64 bits at cur
             uint32_t p = 0;
             uint32_t packed = len | (vtype << 8);            // what a hop needs to know about a candidate
@@ -500,7 +508,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                         bool cut = false;
                         if (!SAFE) {
                             const uint64_t room = limit > here ? (limit - here - 1) >> 1 : 0;   // points of 2 bits that end before the limit
-                            const uint64_t left = cap - n - qn - found;                        // and fit the capacity
+                            const uint32_t left = cap - n - qn - found;                        // and fit the capacity
                             if (zpairs > room) { zpairs = (uint32_t)room; cut = true; }
                             if (zpairs > left) { zpairs = (uint32_t)left; cut = true; }
                         }
@@ -626,7 +634,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                 d.widx = (uint32_t)(pos >> 6); d.off = (uint32_t)pos & 63u;
                 d.r0 = src(d.widx); d.r1 = src(d.widx + 1); d.r2 = src(d.widx + 2); d.r3 = src(d.widx + 3);
                 d.st = 0;
-                d.block_ts = block_ts; d.stored_delta = stored_delta; d.stored_ts = stored_ts; d.val = val; d.pred_last = 0;
+                d.block_ts = (int64_t)src(0); d.stored_delta = stored_delta; d.stored_ts = stored_ts; d.val = val; d.pred_last = 0;
                 d.lead = nbits ? (uint32_t)(64 - (int32_t)nbits - trail) : NO_WINDOW;
                 d.trail = trail;
             }

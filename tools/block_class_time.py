@@ -13,6 +13,7 @@ classes = {
     "constant": np.full(N, 123.456),
     "counter": (rng.integers(0, 1000) + np.cumsum(rng.integers(0, 5, size=N))).astype(np.float64),
     "random_walk": 100.0 + np.cumsum(rng.standard_normal(N)),
+    "readme": np.arange(N, dtype=np.float64),   # G/benchmark/EncodingBenchmark.java:60-69: value = (double) i
     "drift": np.round((rng.random() * 1000 + np.cumsum(rng.standard_normal(N) * 0.05)) * 100) / 100,
     "gauge": 500.0 + np.cumsum(rng.integers(-1, 2, N) * (rng.random(N) < 0.1)),
     "random_bits": rng.integers(0, 2 ** 63, N).astype(np.uint64).view(np.float64),
