@@ -546,7 +546,33 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                     last_len = l;
                 }
             };
-            if (safe) walk(std::true_type{}); else walk(std::false_type{});
+            if (safe) {
+                // Every candidate works out its own hop beforehand -- a run of unchanged points ('00' each,
+                // counted inside the 64 positions) or its length -- and the starts it stands for, so that a
+                // hop of the scalar chain is three lane reads, an OR and an add.
+                const uint32_t zbits = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
+                const uint32_t zp = (zbits < 64u - lane ? zbits : 64u - lane) >> 1;
+                const uint64_t own = zp ? (0x5555555555555555ull >> (64u - 2u * zp)) << lane : 1ull << lane;
+                uint32_t hop = zp ? (2u * zp) | 0x200u : len | (vtype == 2 ? 0x100u : 0u);
+                uint32_t k = 0;
+                while (p < 64) {
+                    k = read_lane(hop, p);
+                    real |= read_lane(own, p);
+                    if (k & 0x100u) {
+                        // a new window from here on: candidates that reuse the window change length
+                        wnb = read_lane(own_sig, p);
+                        wtr = (int32_t)read_lane((uint32_t)own_trail, p);
+                        len = fixed + (vtype == 1 ? wnb : 0u);
+                        hop = zp ? hop : len | (vtype == 2 ? 0x100u : 0u);
+                        if (lane > p) { lane_nb = wnb; lane_tr = wtr; }
+                    }
+                    p += k & 255u;
+                }
+                found = (uint32_t)__builtin_popcountll(real);
+                last_len = (k & 0x200u) ? 2u : (k & 255u);
+            } else {
+                walk(std::false_type{});
+            }
             adv = p;
             }
             // queue the real starts
