@@ -89,8 +89,9 @@ struct gtsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // the one launches go to
-    // device block of FLAG_BLOCK_BYTES: word 0 = OR of status bits raised since the last sync; at byte 8 two
-    // 64-bit counts of what the decoder read and stored since then (compressed words, points)
+    // device block of FLAG_BLOCK_BYTES: word 0 = OR of status bits raised since the last sync; at byte 8 three
+    // 64-bit counts of a sample of the decoder's waves since then: compressed words read, points stored, and
+    // the wave-per-block kernel's steps (low half) and the points they found (high half)
     uint32_t* d_flags = nullptr;
     uint32_t* h_flags = nullptr;    // pinned mirror
     // The host entry points raise their status bits in a block of their own (the second
@@ -104,6 +105,7 @@ struct gtsc_ctx {
     uint64_t* noalloc_scratch = nullptr;  // this device's copy of the library's static scratch array
     bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
     int forced_ring = 0;            // gtsc_set_decode_ring: 0 = by density, 8 or 16 = always that form
+    uint64_t long_blocks_max = 0;   // batches of up to this many long blocks go to the wave-per-block decoder (0: the kernels' own figure)
     DeviceBuf scan_scratch;
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
     int predictor = GTSC_PRED_LAST;
@@ -275,6 +277,13 @@ int gtsc_sync(gtsc_ctx* c)
     {   // how dense were the streams decoded since the last sync: the next decodes use the ring that suits them
         const uint64_t* counts = reinterpret_cast<const uint64_t*>(c->h_flags) + 1;
         if (counts[1] && !c->forced_ring) c->deep_ring = counts[0] * 64 > counts[1] * DENSE_BITS_PER_POINT;
+        // and how many points a step of the wave-per-block decoder found: batches of about a thousand long
+        // blocks per point are where it breaks even with the lane-per-series kernel
+        const uint64_t steps = counts[2] & 0xFFFFFFFFull, found = counts[2] >> 32;
+        if (steps) {
+            const uint64_t m = 1024 * found / steps;
+            c->long_blocks_max = m < 2048 ? 2048 : m > 16384 ? 16384 : m;
+        }
     }
     if (f & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", f);
     if (f & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series overflowed their output slot");
@@ -360,7 +369,7 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
                  out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, c->forced_ring == 16 ? 2u : (c->deep_ring ? 1u : 0u),
-                 reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count};
+                 reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count, c->long_blocks_max};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -667,7 +676,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
                      st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
                      (c->forced_ring ? (c->forced_ring == 16 ? 2u : 0u) : (nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u)) /* the host form knows the density */,
                      nullptr,
-                     ~0ull, nullptr, 0, c->d_long_count + 1};
+                     ~0ull, nullptr, 0, c->d_long_count + 1, c->long_blocks_max};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, c->work, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, c->work));
         HIP_TRY(hipEventRecord(st.coded, c->work));

@@ -405,13 +405,16 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     uint64_t cur = pos;               // walk position (pos is the committed one, where queue entry 0 starts)
     uint32_t wnb = nbits; int32_t wtr = trail;   // window at the walk position
     uint32_t last_len = 0;            // length of the last point the walk passed
+    bool last_reuse = false;          // it reused the value window ('10')
     uint32_t last_found = 0;          // points the last step found, if it went by strides
     uint32_t hold = 0;                // steps for which sparse windows stay with bit positions
     bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
     bool clean_end = finished;
 
+    uint32_t steps = 0;               // for the library's figure of how the kernel fares on these streams
     while (!(stop && qn == 0)) {
         if (!stop) {
+            steps++;
             // ---- one step: 64 candidate starts.  Sparse streams: the 64 bit positions from cur on.
             // Streams of equal-sized points: the positions cur + j * stride -- while the points that
             // follow have the predicted form, all 64 candidates are real starts.
@@ -422,7 +425,9 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
             // Windows under 29 bits: 64 bit positions hold several points, so strides are only taken
             // while they find more than that (a counter's stream -- '10' and a payload of equal size at
             // every point -- goes 64 points a step; one with unchanged values mixed in does not).
-            const uint32_t pstride = 3u + wnb;   // (found * pstride > 64: more points than 64 bit positions hold)
+            // After a point of the predicted kind the stride is that point's length (whatever its timestamp
+            // bucket), after any other 3 + window bits.
+            const uint32_t pstride = last_reuse ? last_len : 3u + wnb;   // (found * pstride > 64: more points than 64 bit positions hold)
             const bool strided = wnb == 0   ? false
                                  : wnb >= 29 ? (last_len >= 32 || last_found >= 2)
                                              : (hold == 0 && (last_len == pstride || last_found * pstride > 64u));
@@ -479,6 +484,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                         found = js + 1;
                         adv += l;
                         last_len = l;
+                        last_reuse = read_lane(vtype, js) == 1;
                         if (read_lane(vtype, js) == 2) {
                             wnb = read_lane(own_sig, js);
                             wtr = (int32_t)read_lane((uint32_t)own_trail, js);
@@ -518,6 +524,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                             found += zpairs;
                             p += 2 * zpairs;
                             last_len = 2;
+                            last_reuse = false;
                         }
                         if (cut) { stop = true; break; }
                         continue;
@@ -544,6 +551,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                     }
                     p += l;
                     last_len = l;
+                    last_reuse = ty == 1;
                 }
             };
             if (safe) {
@@ -553,7 +561,7 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                 const uint32_t zbits = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
                 const uint32_t zp = (zbits < 64u - lane ? zbits : 64u - lane) >> 1;
                 const uint64_t own = zp ? (0x5555555555555555ull >> (64u - 2u * zp)) << lane : 1ull << lane;
-                uint32_t hop = zp ? (2u * zp) | 0x200u : len | (vtype == 2 ? 0x100u : 0u);
+                uint32_t hop = zp ? (2u * zp) | 0x200u : len | (vtype == 2 ? 0x100u : vtype == 1 ? 0x400u : 0u);
                 uint32_t k = 0;
                 while (p < 64) {
                     k = read_lane(hop, p);
@@ -563,13 +571,14 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
                         wnb = read_lane(own_sig, p);
                         wtr = (int32_t)read_lane((uint32_t)own_trail, p);
                         len = fixed + (vtype == 1 ? wnb : 0u);
-                        hop = zp ? hop : len | (vtype == 2 ? 0x100u : 0u);
+                        hop = zp ? hop : len | (vtype == 2 ? 0x100u : vtype == 1 ? 0x400u : 0u);
                         if (lane > p) { lane_nb = wnb; lane_tr = wtr; }
                     }
                     p += k & 255u;
                 }
                 found = (uint32_t)__builtin_popcountll(real);
                 last_len = (k & 0x200u) ? 2u : (k & 255u);
+                last_reuse = (k & 0x400u) != 0;
             } else {
                 walk(std::false_type{});
             }
@@ -676,6 +685,14 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
         a.out_npoints[s] = n;
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
+        // what the block read and produced, for the library's density figure (one block in 64 reports, as
+        // one wave in 64 of the lane-per-series kernel does)
+        if (a.stats && (s & 63u) == 0) {
+            const uint64_t words = pos >> 6;
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats), (unsigned long long)(words < nw ? words : nw));
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 1, (unsigned long long)(n < cap ? n : cap));
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 2, (unsigned long long)steps | ((unsigned long long)(n < cap ? n : cap) << 32));
+        }
     }
     wave_sync();
 }

@@ -1234,17 +1234,17 @@ static bool deep_ring_pays(uint32_t waves)
 }
 
 // Up to how many long blocks a batch is decoded by the wave-per-block kernel.  That kernel's time grows
-// with the number of blocks (0.10-0.28 us per 7,200-point block with all units busy, by kind of
-// stream), the lane-per-series kernel's does not until every SIMD has a wave (it is the time one lane
-// needs for its series, 0.4 us per 1,000 points): 12,288 is where the slowest kind of stream
-// (drifting gauges) breaks even; sparse gauges would at 20,000, random walks at 32,000.
-static uint64_t long_decode_max()
+// with the number of blocks (0.09-0.18 us per 7,200-point block with all units busy for streams it
+// reads in strides or runs, 0.9 us for one of irregular long points), the lane-per-series kernel's does
+// not until every SIMD has a wave (it is the time one lane needs for its series, 0.4 us per 1,000
+// points).  The break-even count goes with the points the kernel finds per step -- about a thousand
+// blocks per point -- so the caller passes a figure made from what the kernel reported about the
+// batches before (DecodeArgs::stats[2]); without one, 12,288.
+static uint64_t long_decode_max(const DecodeArgs& a)
 {
-    static const uint64_t v = [] {
-        const char* e = getenv("GTSC_LONG_DECODE_MAX");
-        return e ? strtoull(e, nullptr, 10) : 12288ull;
-    }();
-    return v;
+    static const char* const e = getenv("GTSC_LONG_DECODE_MAX");
+    static const uint64_t forced = e ? strtoull(e, nullptr, 10) : 0;
+    return e ? forced : a.long_blocks_max ? a.long_blocks_max : 12288ull;
 }
 
 hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
@@ -1254,7 +1254,7 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
     a.long_threshold = ~0ull; a.long_count = nullptr; a.long_max_series = 0;
     if (!a.dfcm_tables && !use_direct_kernels()) {
         if (!a.pts.off) {
-            if (a.pts.uniform >= long_points() && a.nseries <= long_decode_max()) {
+            if (a.pts.uniform >= long_points() && a.nseries <= long_decode_max(a)) {
                 a.long_threshold = 0;  // a uniform batch of few long blocks: all of it is the wave-per-block kernel's
                 return launch_decode_blocks(a, format, stream);
             }
@@ -1262,7 +1262,7 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
             // per-series capacities are only known on the device: count the long ones, then both kernels
             // run over the batch and each takes its side
             a.long_threshold = long_points();
-            a.long_max_series = long_decode_max();
+            a.long_max_series = long_decode_max(a);
             a.long_count = a.long_count_buf;
             if (hipError_t e = launch_count_long(a.nseries, a.pts, a.long_threshold, a.long_count_buf, stream)) return e;
             if (hipError_t e = launch_decode_blocks(a, format, stream)) return e;

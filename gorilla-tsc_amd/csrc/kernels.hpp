@@ -44,7 +44,7 @@ struct DecodeArgs {
     uint32_t dfcm_mask;
     uint32_t group_shift;     // as in EncodeArgs
     uint32_t deep_ring;       // the tiled kernel's input rings: 0 = 8 words; 1 = the streams are dense, 16 words unless the batch's waves fill the units better with 8; 2 = 16 words
-    uint64_t* stats;          // may be null: [0] += words read, [1] += points stored
+    uint64_t* stats;          // may be null: [0] += words read, [1] += points stored (a sample of the waves); [2] += steps | points << 32 of a sample of the wave-per-block kernel's blocks
     // Series whose capacity is at least long_threshold points are decoded by the wave-per-block kernel and left
     // alone by the lane-per-series kernels (~0: none) -- provided the batch holds at most long_max_series of
     // them, which both kernels read from *long_count (null: no such condition).  Set by the launcher.
@@ -52,6 +52,7 @@ struct DecodeArgs {
     const uint64_t* long_count;
     uint64_t long_max_series;
     uint64_t* long_count_buf; // from the caller: one device word the launcher may use for the count (may be null)
+    uint64_t long_blocks_max; // from the caller: up to how many long blocks a batch goes to the wave-per-block kernel (0: the built-in figure)
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);

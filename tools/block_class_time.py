@@ -18,9 +18,15 @@ classes = {
     "gauge": 500.0 + np.cumsum(rng.integers(-1, 2, N) * (rng.random(N) < 0.1)),
     "random_bits": rng.integers(0, 2 ** 63, N).astype(np.uint64).view(np.float64),
 }
+# the same values at scrape times that are a few ms off the cadence (timestamp codes of 9 to 16 bits instead of '0')
+classes["jitter_gauge"] = classes["gauge"]
+classes["jitter_walk"] = classes["random_walk"]
+classes["jitter_counter"] = classes["counter"]
 ctx = G.Context(0)
 for name, v in classes.items():
     ts = synth.BLOCK_TS + 1000 * np.arange(1, N + 1, dtype=np.int64)
+    if name.startswith("jitter_"):
+        ts = ts + rng.integers(-40, 41, N)
     val = np.ascontiguousarray(v).view(np.uint64)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
     d_block, d_ts, d_val = d(np.array([synth.BLOCK_TS], dtype=np.int64)), d(ts), d(val)
