@@ -220,9 +220,6 @@ constexpr uint32_t RING_TRIGGER = RING_WORDS - 4;
 #ifndef GTSC_LAND_LOW
 #define GTSC_LAND_LOW 5u
 #endif
-#ifndef GTSC_LAND_AGE
-#define GTSC_LAND_AGE 5u
-#endif
 #ifndef GTSC_LDS_PAD
 #define GTSC_LDS_PAD 0
 #endif
@@ -859,16 +856,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             GTSC_POINT(1)
             if constexpr (RING == 8) {
                 if (pend) GTSC_TOPUP_LAND()
+                const bool low = d.widx >= limit;
+                if (low) GTSC_TOPUP_ISSUE()
             } else {
-                // pend counts the checks a top-up has been in flight: it lands when its lane is down to
-                // five unread words or the load is five checks old (all that are in flight land with it;
-                // measured: landing earlier waits more often, landing later starves the densest lanes)
-                const bool due = pend != 0 && (filled - d.widx <= GTSC_LAND_LOW || pend >= GTSC_LAND_AGE);
-                if (any_lane(due)) { GTSC_LAND_STAMP() if (pend) GTSC_TOPUP_LAND() }
-                else pend += pend ? 1u : 0u;
+                // requests are made at every second check only, and land at the next such check: what the wave
+                // waits for then is two checks old in every lane.  In between only a lane about to run out lands.
+                if (k2 & 1u) {
+                    if (pend) { GTSC_LAND_STAMP() GTSC_TOPUP_LAND() }
+                    const bool low = d.widx >= limit;
+                    if (low) GTSC_TOPUP_ISSUE()
+                } else {
+                    const bool due = pend != 0 && filled - d.widx <= GTSC_LAND_LOW;
+                    if (any_lane(due)) {
+                        GTSC_LAND_STAMP()
+                        if (pend) GTSC_TOPUP_LAND()
+                        const bool low = d.widx >= limit;
+                        if (low) GTSC_TOPUP_ISSUE()
+                    }
+                }
             }
-            const bool low = d.widx >= limit;
-            if (low) GTSC_TOPUP_ISSUE()
         }
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
         if (active && c * DCH >= cap) { active = false; nfin = n; }
