@@ -131,7 +131,7 @@ EXTRA_WORKLOADS = [
 
 def other_workloads(measure, ctx):
     """The configurations the headline does not cover, each compress + decompress device-resident like the
-    headline (5 timed steps after 3), plus one 7,200-point block alone and the host-to-host rates."""
+    headline (5 timed steps after 3), plus batches of one or a few long blocks and the host-to-host rates."""
     out = {}
     for key, wl, S, P in EXTRA_WORKLOADS:
         try:
@@ -150,51 +150,61 @@ def other_workloads(measure, ctx):
             "compressed_bits_per_point": round(64.0 * m["total_words"] / (S * P), 3),
         }
         torch.cuda.empty_cache()
-    try:
-        out["one_block_7200_random_walk"] = one_block(ctx)
-    except Exception as e:
-        out["one_block_7200_random_walk"] = {"error": repr(e)[:200]}
+    # batches too small to fill the GPU: the reference's own block, and the reference benchmark's data
+    # (G/benchmark/EncodingBenchmark.java:49,60-69: 100,000 points of (double) i) as one block and as 1,024
+    for key, make in (("one_block_7200_random_walk", lambda: synth.random_walk(S=1, P=7200)),
+                      ("readme_1x100000", lambda: synth.readme_workload(S=1, P=100000)),
+                      ("readme_1024x100000", lambda: synth.readme_workload(S=1024, P=100000))):
+        try:
+            out[key] = few_blocks(ctx, make())
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     return out
 
 
-def one_block(ctx):
-    """One series, one 2-hour block at 1 s cadence (7,200 random-walk doubles): the reference's own use.
-    GPU: wall time of a device-resident compress and decompress call incl. launch and sync; CPU: the C
-    oracle, one thread."""
+def few_blocks(ctx, b, cpu_reps=5):
+    """A batch too small to fill the GPU -- one 2-hour block of 7,200 random-walk doubles (the reference's own
+    use), or the reference benchmark's 100,000-point blocks.  GPU: wall time of a device-resident compress and
+    decompress call incl. launch and sync; CPU: the C oracle, one thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as O
-    b = synth.random_walk(S=1, P=7200)
+    S, P = b.block_ts.size, int(b.pt_off[1] - b.pt_off[0])
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
     d_block, d_ts, d_val = d(b.block_ts), d(b.ts), d(b.val)
-    slot = G.max_words(7200)
-    d_out = torch.zeros(slot, dtype=torch.int64, device="cuda")
-    d_nw = torch.zeros(1, dtype=torch.int64, device="cuda")
+    slot = G.max_words(P)
+    d_out = torch.zeros(S * slot, dtype=torch.int64, device="cuda")
+    d_nw = torch.zeros(S, dtype=torch.int64, device="cuda")
     d_ts2, d_val2 = torch.zeros_like(d_ts), torch.zeros_like(d_val)
-    d_np = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d_np = torch.zeros(S, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     te = td = 1e9
     for _ in range(20):
         t0 = time.perf_counter()
-        ctx.encode_device(d_block, d_ts, d_val, d_out, d_nw, uniform_npoints=7200, uniform_slot_words=slot)
+        ctx.encode_device(d_block, d_ts, d_val, d_out, d_nw, uniform_npoints=P, uniform_slot_words=slot)
         ctx.sync()
         t1 = time.perf_counter()
-        ctx.decode_device(d_out, d_ts2, d_val2, d_np, 1, uniform_slot_words=slot, in_nwords=d_nw, uniform_capacity=7200)
+        ctx.decode_device(d_out, d_ts2, d_val2, d_np, S, uniform_slot_words=slot, in_nwords=d_nw, uniform_capacity=P)
         ctx.sync()
         t2 = time.perf_counter()
         te, td = min(te, t1 - t0), min(td, t2 - t1)
     assert torch.equal(d_ts2, d_ts) and torch.equal(d_val2, d_val)
+    # the CPU side on one block of the batch (they are all alike in these batches)
+    one = synth.Batch(b.block_ts[:1], b.ts[:P], b.val[:P], b.pt_off[:2])
     ce = cd = 1e9
-    for _ in range(5):
+    for _ in range(cpu_reps):
         t0 = time.perf_counter()
-        w, off, nw, _ = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, nthreads=1)
+        w, off, nw, _ = O.encode_batch(one.block_ts, one.ts, one.val, one.pt_off, nthreads=1)
         t1 = time.perf_counter()
-        O.decode_batch(w, off, nw, b.pt_off, nthreads=1)
+        O.decode_batch(w, off, nw, one.pt_off, nthreads=1)
         t2 = time.perf_counter()
         ce, cd = min(ce, t1 - t0), min(cd, t2 - t1)
     assert np.array_equal(d_out.cpu().numpy().view(np.uint64)[: int(nw[0])], w[: int(nw[0])])
-    return {"gpu_compress_us": round(te * 1e6, 1), "gpu_decompress_us": round(td * 1e6, 1),
-            "cpu_port_one_thread_compress_us": round(ce * 1e6, 1), "cpu_port_one_thread_decompress_us": round(cd * 1e6, 1),
-            "note": "GPU figures are whole calls (launch + sync), best of 20; CPU best of 5"}
+    return {"blocks": S, "points_per_block": P,
+            "gpu_compress_us": round(te * 1e6, 1), "gpu_decompress_us": round(td * 1e6, 1),
+            "cpu_port_one_thread_compress_us_per_block": round(ce * 1e6, 1),
+            "cpu_port_one_thread_decompress_us_per_block": round(cd * 1e6, 1),
+            "note": "GPU figures are whole calls over all blocks (launch + sync), best of 20; CPU one block, best of %d" % cpu_reps}
 
 
 def host_to_host():

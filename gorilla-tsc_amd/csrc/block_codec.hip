@@ -157,54 +157,80 @@ struct ChunkCarry {
     uint64_t t1, t2, v1;        // the two timestamps and the value before the chunk's lane 0
 };
 
+// What a lane knows about its point before the value window is settled.
+struct PointPrep {
+    uint64_t t, v, x;           // timestamp, value, XOR with the previous value
+    uint64_t tcode;             // timestamp code and its length
+    uint32_t tlen;
+    uint32_t lz, tz;            // leading / trailing zeros of x (leading ones capped for the 1.x format)
+    bool active, first, nz;     // a point at all; written as a "first" point; changed value
+};
+
+// Lane l holds point i0 + l of the block (t, v), if that is a point at all; t1, t2, v1 are the
+// two timestamps and the value before it.
+template <int FMT>
+__device__ __forceinline__ PointPrep prepare_point(uint64_t t, uint64_t v, uint64_t t1, uint64_t t2, uint64_t v1, int32_t i,
+                                                   uint32_t np, int64_t bts)
+{
+    PointPrep p;
+    p.t = t; p.v = v;
+    p.active = (uint32_t)i < np;
+    // "first" is whoever follows a stored timestamp of zero (G/GorillaCompressor.java:50,65)
+    p.first = i == 0 || t1 == 0;
+    const bool prev_first = i == 1 || t2 == 0;
+    p.tcode = 0; p.tlen = 1;  // regular cadence: the single bit '0'
+    if (FMT == FMT_V2) {
+        const uint32_t sd = (uint32_t)t1 - (prev_first ? (uint32_t)bts : (uint32_t)t2);
+        if (any_lane(p.active && !p.first && (uint32_t)t - (uint32_t)t1 != sd)) ts_code_v2((uint32_t)t, (uint32_t)t1, sd, p.tcode, p.tlen);
+    } else {
+        const uint64_t sd = t1 - (prev_first ? (uint64_t)bts : t2);
+        if (any_lane(p.active && !p.first && t - t1 != sd)) ts_code_v1(t, t1, sd, p.tcode, p.tlen);
+    }
+    p.x = v ^ v1;
+    p.nz = p.active && !p.first && p.x != 0;
+    p.lz = (uint32_t)__clzll((long long)p.x);
+    p.tz = (uint32_t)(__ffsll((long long)p.x) - 1);
+    if (FMT == FMT_V1) p.lz = p.lz >= 32 ? 31u : p.lz;     // G/Compressor.java:132-134
+    return p;
+}
+
+// The lane's code once the window that holds at its point (wl, wt) is known, and whether the point opens it.
+template <int FMT>
+__device__ __forceinline__ LaneCode point_code(const PointPrep& p, uint32_t wl, uint32_t wt, bool fresh, int64_t bts)
+{
+    const bool reuse = p.nz && !fresh;
+    const uint32_t sig = 64u - p.lz - p.tz;
+    const uint32_t vh_new = (FMT == FMT_V2) ? ((3u << 12) | (p.lz << 6) | (sig - 1u)) : ((3u << 11) | (p.lz << 6) | (sig & 63u));
+    const uint32_t vh = p.nz ? (reuse ? 2u : vh_new) : 0u;
+    const uint32_t vhlen = p.nz ? (reuse ? 2u : (FMT == FMT_V2 ? 14u : 13u)) : 1u;
+    LaneCode code;
+    code.head = p.active ? (p.tcode << vhlen) | vh : 0ull;
+    code.hlen = p.active ? p.tlen + vhlen : 0u;
+    code.pay = p.nz ? p.x >> ((reuse ? wt : p.tz) & 63u) : 0ull;
+    code.plen = p.nz ? (reuse ? 64u - wl - wt : sig) : 0u;
+    if (any_lane(p.active && p.first)) {
+        // writeFirst: 27 low bits of the delta to the block timestamp, then the raw value
+        if (p.active && p.first) {
+            code.head = (p.t - (uint64_t)bts) & 0x7FFFFFFull; code.hlen = 27;
+            code.pay = p.v; code.plen = 64;
+        }
+    }
+    return code;
+}
+
 // Codes one chunk: lane l holds point i0 + l of the block (t, v), if that is a point at all.
 template <int FMT>
 __device__ __forceinline__ void encode_chunk(BlockWriter& w, ChunkCarry& k, uint64_t t, uint64_t v, int32_t i0, uint32_t np,
                                              int64_t bts, uint32_t lane)
 {
-    const int32_t i = i0 + (int32_t)lane;
-    const bool active = (uint32_t)i < np;
     const uint64_t t1 = lane_shift_up(t, k.t1);
     const uint64_t t2 = lane_shift_up(t1, k.t2);
     const uint64_t v1 = lane_shift_up(v, k.v1);
     k.t1 = read_lane(t, 63); k.t2 = read_lane(t1, 63); k.v1 = read_lane(v, 63);
-    // "first" is whoever follows a stored timestamp of zero (G/GorillaCompressor.java:50,65)
-    const bool first = i == 0 || t1 == 0;
-    const bool prev_first = i == 1 || t2 == 0;
-
-    uint64_t tcode = 0; uint32_t tlen = 1;  // regular cadence: the single bit '0'
-    if (FMT == FMT_V2) {
-        const uint32_t sd = (uint32_t)t1 - (prev_first ? (uint32_t)bts : (uint32_t)t2);
-        if (any_lane(active && !first && (uint32_t)t - (uint32_t)t1 != sd)) ts_code_v2((uint32_t)t, (uint32_t)t1, sd, tcode, tlen);
-    } else {
-        const uint64_t sd = t1 - (prev_first ? (uint64_t)bts : t2);
-        if (any_lane(active && !first && t - t1 != sd)) ts_code_v1(t, t1, sd, tcode, tlen);
-    }
-    const uint64_t x = v ^ v1;
-    const bool nz = active && !first && x != 0;
-    uint32_t lz = (uint32_t)__clzll((long long)x);
-    const uint32_t tz = (uint32_t)(__ffsll((long long)x) - 1);
-    if (FMT == FMT_V1) lz = lz >= 32 ? 31u : lz;           // G/Compressor.java:132-134
+    const PointPrep p = prepare_point<FMT>(t, v, t1, t2, v1, i0 + (int32_t)lane, np, bts);
     uint32_t wl, wt; bool fresh;
-    resolve_window(nz, lz, tz, lane, k.lead, k.trail, wl, wt, fresh);
-    const bool reuse = nz && !fresh;
-    const uint32_t sig = 64u - lz - tz;
-    const uint32_t vh_new = (FMT == FMT_V2) ? ((3u << 12) | (lz << 6) | (sig - 1u)) : ((3u << 11) | (lz << 6) | (sig & 63u));
-    const uint32_t vh = nz ? (reuse ? 2u : vh_new) : 0u;
-    const uint32_t vhlen = nz ? (reuse ? 2u : (FMT == FMT_V2 ? 14u : 13u)) : 1u;
-    LaneCode code;
-    code.head = active ? (tcode << vhlen) | vh : 0ull;
-    code.hlen = active ? tlen + vhlen : 0u;
-    code.pay = nz ? x >> ((reuse ? wt : tz) & 63u) : 0ull;
-    code.plen = nz ? (reuse ? 64u - wl - wt : sig) : 0u;
-    if (any_lane(active && first)) {
-        // writeFirst: 27 low bits of the delta to the block timestamp, then the raw value
-        if (active && first) {
-            code.head = (t - (uint64_t)bts) & 0x7FFFFFFull; code.hlen = 27;
-            code.pay = v; code.plen = 64;
-        }
-    }
-    w.append(code, lane);
+    resolve_window(p.nz, p.lz, p.tz, lane, k.lead, k.trail, wl, wt, fresh);
+    w.append(point_code<FMT>(p, wl, wt, fresh, bts), lane);
 }
 
 // Compresses block `s` with the whole wave.
@@ -301,6 +327,187 @@ __global__ __launch_bounds__(64) void encode_block_kernel(EncodeArgs a, uint32_t
     }
 }
 
+
+// ------------------------------------------------------------------------
+// Cooperative form of the compressor for batches of so few blocks that a wave per block leaves the
+// machine empty: a workgroup of COOP_WAVES waves per block (all on one compute unit: the waves talk through LDS).  Wave w of round r takes chunk
+// r * COOP_WAVES + w (64 points).  Everything but the window and the bit position is worked out by
+// the waves side by side; those two pass from chunk to chunk through two mailboxes in LDS: a wave
+// waits for its predecessor's window, settles its chunk's windows and hands the window on; works
+// out its codes and their total length; waits for its predecessor's end position, hands its own on;
+// and packs its codes.  The codes go into a staging ring shared by the workgroup at their absolute bit
+// positions; after each round the words the round has completed leave for HBM.
+// ------------------------------------------------------------------------
+// LDS words that waves of a workgroup exchange: plain accesses the compiler may neither merge nor move
+// every LDS access this wave has made so far has been carried out
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+constexpr uint32_t COOP_WAVES = 16;        // measured on a lone 100,000-point block: 4 waves 0.63 ms, 8 0.49, 16 0.43 (one wave: 0.94)
+constexpr uint32_t COOP_STAGE_WORDS = COOP_WAVES * 128;   // a round's codes (64 x 114 bits = 114 words per chunk at most) and the word before them
+
+struct CoopLds {
+    uint64_t stage[COOP_STAGE_WORDS];   // image word i lives in stage[i % COOP_STAGE_WORDS] until it is written out
+    // Two mailboxes, one 64-bit word each so that a single read tells whether it is meant for the reader:
+    uint64_t win;   // chunk number << 32 | trailing zeros << 16 | leading zeros: the value window where that chunk begins
+    uint64_t pos;   // chunk number << 38 | the bit position where that chunk's codes begin (2^31 points of 114 bits fit 38 bits,
+                    // their 2^25 chunks the 26 above)
+};
+constexpr uint32_t COOP_POS_BITS = 38;
+constexpr uint64_t COOP_POS_MASK = (1ull << COOP_POS_BITS) - 1;
+
+__device__ __forceinline__ uint64_t lds_peek64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_poke64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t x)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64 * COOP_WAVES) void encode_block_coop_kernel(EncodeArgs a)
+{
+    __shared__ CoopLds L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint64_t s = blockIdx.x;
+    const uint64_t np64 = a.pts.size(s);
+    if (np64 < a.long_threshold) return;   // the lane-per-series kernel's (the whole workgroup leaves together)
+    for (uint32_t i = tid; i < COOP_STAGE_WORDS; i += 64 * COOP_WAVES) L.stage[i] = 0;
+    if (tid == 0) { L.win = NO_WINDOW; L.pos = 64; }   // chunk 0: no window yet, the header word before it
+    __syncthreads();
+
+    const uint64_t p0 = a.pts.begin(s);
+    const uint32_t np = np64 > BLOCK_MAX_POINTS ? BLOCK_MAX_POINTS : (uint32_t)np64;
+    const int64_t bts = a.block_ts[s];
+    uint64_t* const out = a.out_words + a.slots.begin(s);
+    const uint64_t cap = a.slots.size(s);
+    if (tid == 0 && cap > 0) out[0] = (uint64_t)bts;  // addHeader, G/GorillaCompressor.java:39-41
+    const uint32_t phase = (uint32_t)((p0 + ((uintptr_t)a.ts >> 3)) & 63u);
+    const uint32_t nchunks = np ? (uint32_t)(((uint64_t)phase + np + 63) / 64) : 0u;
+    const uint32_t nrounds = (nchunks + COOP_WAVES - 1) / COOP_WAVES;
+    const int64_t* const pt = a.ts + p0;
+    const uint64_t* const pv = a.val + p0;
+    const uint32_t last = np ? np - 1 : 0;
+
+    // A wave's chunks of three rounds are in flight in three sets of registers, loaded from clamped
+    // addresses without conditions (as in encode_block); with each chunk come the two timestamps and
+    // the value before its first point, which another wave's chunk holds.
+    uint64_t tA = 0, vA = 0, tB = 0, vB = 0, tC = 0, vC = 0;
+    uint64_t pA1 = 0, pA2 = 0, qA = 0, pB1 = 0, pB2 = 0, qB = 0, pC1 = 0, pC2 = 0, qC = 0;
+#define GTSC_COOP_LOAD(R, T_, V_, P1_, P2_, Q_)                                                \
+    {                                                                                          \
+        const uint32_t u_ = ((uint32_t)(R) * COOP_WAVES + wave) * 64u;                         \
+        const uint32_t ul_ = u_ + lane;                                                        \
+        const uint32_t d_ = ul_ - phase;                                                       \
+        const uint32_t i_ = ul_ < phase ? 0u : (d_ < last ? d_ : last);                        \
+        T_ = (uint64_t)__builtin_nontemporal_load(pt + i_);                                    \
+        V_ = __builtin_nontemporal_load(pv + i_);                                              \
+        const uint32_t j1_ = u_ < phase + 1u ? 0u : (u_ - phase - 1u < last ? u_ - phase - 1u : last); \
+        const uint32_t j2_ = u_ < phase + 2u ? 0u : (u_ - phase - 2u < last ? u_ - phase - 2u : last); \
+        P1_ = (uint64_t)pt[j1_]; P2_ = (uint64_t)pt[j2_]; Q_ = pv[j1_];                        \
+    }
+    if (np) {
+        GTSC_COOP_LOAD(0, tA, vA, pA1, pA2, qA)
+        GTSC_COOP_LOAD(1, tB, vB, pB1, pB2, qB)
+        GTSC_COOP_LOAD(2, tC, vC, pC1, pC2, qC)
+    }
+    uint64_t flushed = 1;   // image words written out so far (every thread keeps count)
+    unsigned long long* const st = reinterpret_cast<unsigned long long*>(L.stage);
+
+#define GTSC_COOP_ROUND(R, T_, V_, P1_, P2_, Q_)                                               \
+    {                                                                                          \
+        const uint32_t c_ = (uint32_t)(R) * COOP_WAVES + wave;                                 \
+        if (c_ < nchunks) {                                                                    \
+            const int32_t i0_ = (int32_t)(c_ * 64u) - (int32_t)phase;                          \
+            const uint64_t t1_ = lane_shift_up(T_, P1_);                                       \
+            const uint64_t t2_ = lane_shift_up(t1_, P2_);                                      \
+            const uint64_t v1_ = lane_shift_up(V_, Q_);                                        \
+            const PointPrep p_ = prepare_point<FMT>(T_, V_, t1_, t2_, v1_, i0_ + (int32_t)lane, np, bts); \
+            /* the window chain: the predecessor's hand-over, this chunk's windows, on to the successor */ \
+            uint64_t m_;                                                                       \
+            do { m_ = uniform64(lds_peek64(&L.win)); } while ((uint32_t)(m_ >> 32) != c_);     \
+            uint32_t lead_ = (uint32_t)m_ & 0xFFFFu, trail_ = ((uint32_t)m_ >> 16) & 0xFFFFu;  \
+            uint32_t wl_, wt_; bool fresh_;                                                    \
+            resolve_window(p_.nz, p_.lz, p_.tz, lane, lead_, trail_, wl_, wt_, fresh_);        \
+            if (lane == 0) lds_poke64(&L.win, ((uint64_t)(c_ + 1u) << 32) | (trail_ << 16) | lead_); \
+            /* side by side again: codes and their lengths */                                  \
+            const LaneCode code_ = point_code<FMT>(p_, wl_, wt_, fresh_, bts);                 \
+            const uint32_t len_ = code_.hlen + code_.plen;                                     \
+            const uint32_t incl_ = wave_inclusive_sum(len_);                                   \
+            const uint32_t total_ = read_lane(incl_, 63);                                      \
+            /* the position chain */                                                           \
+            uint64_t q_;                                                                       \
+            do { q_ = uniform64(lds_peek64(&L.pos)); } while ((uint32_t)(q_ >> COOP_POS_BITS) != c_);     \
+            const uint64_t pos_ = q_ & COOP_POS_MASK;                                          \
+            if (lane == 0) lds_poke64(&L.pos, ((uint64_t)(c_ + 1u) << COOP_POS_BITS) | (pos_ + total_));  \
+            /* the codes into the ring: 128 bits left-aligned, shifted to their place, three words at most */ \
+            const uint64_t at_ = pos_ + incl_ - len_;                                          \
+            const uint32_t w0_ = (uint32_t)(at_ >> 6), sh_ = (uint32_t)at_ & 63u;              \
+            const uint64_t A_ = code_.head << ((64u - code_.hlen) & 63u);                      \
+            const uint64_t B_ = code_.pay << ((64u - code_.plen) & 63u);                       \
+            const uint64_t hi_ = A_ | (B_ >> code_.hlen);                                      \
+            const uint64_t lo_ = (B_ << 1) << (63u - code_.hlen);                              \
+            const uint64_t x0_ = hi_ >> sh_;                                                   \
+            const uint64_t x1_ = ((hi_ << 1) << (63u - sh_)) | (lo_ >> sh_);                   \
+            const uint64_t x2_ = (lo_ << 1) << (63u - sh_);                                    \
+            if (x0_) atomicOr(st + (w0_ & (COOP_STAGE_WORDS - 1)), (unsigned long long)x0_);   \
+            if (x1_) atomicOr(st + ((w0_ + 1) & (COOP_STAGE_WORDS - 1)), (unsigned long long)x1_); \
+            if (x2_) atomicOr(st + ((w0_ + 2) & (COOP_STAGE_WORDS - 1)), (unsigned long long)x2_); \
+        }                                                                                      \
+        /* the round is packed: its whole words leave (the mailbox holds where it ended) */    \
+        lds_drain();                                                                           \
+        __builtin_amdgcn_s_barrier();                                                          \
+        {                                                                                      \
+            const uint64_t e_ = (uniform64(lds_peek64(&L.pos)) & COOP_POS_MASK) >> 6;           \
+            for (uint64_t w_ = flushed + tid; w_ < e_; w_ += 64 * COOP_WAVES) {                \
+                const uint64_t x_ = L.stage[w_ & (COOP_STAGE_WORDS - 1)];                      \
+                L.stage[w_ & (COOP_STAGE_WORDS - 1)] = 0;                                      \
+                if (w_ < cap) out[w_] = x_;                                                    \
+            }                                                                                  \
+            flushed = e_;                                                                      \
+        }                                                                                      \
+        lds_drain();                                                                           \
+        __builtin_amdgcn_s_barrier();                                                          \
+    }
+    for (uint32_t r = 0; r < nrounds; r += 3) {
+        GTSC_COOP_ROUND(r, tA, vA, pA1, pA2, qA)
+        GTSC_COOP_LOAD(r + 3, tA, vA, pA1, pA2, qA)
+        if (r + 1 < nrounds) GTSC_COOP_ROUND(r + 1, tB, vB, pB1, pB2, qB)
+        GTSC_COOP_LOAD(r + 4, tB, vB, pB1, pB2, qB)
+        if (r + 2 < nrounds) GTSC_COOP_ROUND(r + 2, tC, vC, pC1, pC2, qC)
+        GTSC_COOP_LOAD(r + 5, tC, vC, pC1, pC2, qC)
+    }
+#undef GTSC_COOP_ROUND
+#undef GTSC_COOP_LOAD
+    if (wave != 0) return;
+    // ---- wave 0: close marker, the partial word and the zero word(s) of getLongArray()
+    uint64_t nbits = uniform64(lds_peek64(&L.pos)) & COOP_POS_MASK;
+    if (!a.no_close) {
+        // close(): '1111' + 32 ones + '0' (G/GorillaCompressor.java:84-89)
+        if (lane == 0) {
+            const uint64_t m = 0xFFFFFFFFFull << 1;   // 37 bits
+            const uint32_t w0 = (uint32_t)(nbits >> 6), sh = (uint32_t)nbits & 63u;
+            const uint64_t hi = m << 27;              // left-aligned
+            L.stage[w0 & (COOP_STAGE_WORDS - 1)] |= hi >> sh;
+            L.stage[(w0 + 1) & (COOP_STAGE_WORDS - 1)] |= (hi << 1) << (63u - sh);
+        }
+        nbits += 37;
+        wave_sync();
+    }
+    const uint64_t wcount = nbits >> 6;               // whole words of the stream
+    const uint64_t nwords = wcount + (a.no_close ? 1 : 2);
+    if (lane == 0) {
+        // (at most one whole word is left beside the partial one: the marker is shorter than a word)
+        for (uint64_t w = flushed; w <= wcount; w++)
+            if (w < cap) out[w] = L.stage[w & (COOP_STAGE_WORDS - 1)];
+        if (!a.no_close && wcount + 1 < cap) out[wcount + 1] = 0;
+        const uint32_t stt = (nwords > cap || np64 > BLOCK_MAX_POINTS) ? ST_OVERFLOW : 0u;
+        a.out_nwords[s] = nwords;
+        if (a.out_nbits) a.out_nbits[s] = nbits;
+        if (a.status) a.status[s] = stt;
+        if (stt) atomicOr(a.flags, stt);
+    }
+}
 
 // ------------------------------------------------------------------------
 // Decompressor.  Where a point starts is only known by decoding what precedes it, so the chain
@@ -728,6 +935,13 @@ __global__ __launch_bounds__(256) void count_long_kernel(uint64_t nseries, Layou
 hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream)
 {
     if (a.nseries == 0) return hipSuccess;
+    // so few blocks that a wave each would leave most SIMDs empty: a workgroup of sixteen waves each
+    static const uint64_t coop_max = [] { const char* e = getenv("GTSC_COOP_MAX"); return e ? strtoull(e, nullptr, 10) : 256ull; }();
+    if (a.nseries <= coop_max) {
+        if (format == FMT_V2) hipLaunchKernelGGL(encode_block_coop_kernel<FMT_V2>, dim3((uint32_t)a.nseries), dim3(64 * COOP_WAVES), 0, stream, a);
+        else                  hipLaunchKernelGGL(encode_block_coop_kernel<FMT_V1>, dim3((uint32_t)a.nseries), dim3(64 * COOP_WAVES), 0, stream, a);
+        return hipGetLastError();
+    }
     // enough waves to fill the machine several times over when there are that many series
     uint64_t per_wave = a.nseries / 8192;
     per_wave = per_wave < 1 ? 1 : per_wave > 64 ? 64 : per_wave;
