@@ -332,35 +332,36 @@ __global__ __launch_bounds__(64) void encode_block_kernel(EncodeArgs a, uint32_t
 // Cooperative form of the compressor for batches of so few blocks that a wave per block leaves the
 // machine empty: a workgroup of COOP_WAVES waves per block (all on one compute unit: the waves talk through LDS).  Wave w of round r takes chunk
 // r * COOP_WAVES + w (64 points).  Everything but the window and the bit position is worked out by
-// the waves side by side; those two pass from chunk to chunk through two mailboxes in LDS: a wave
-// waits for its predecessor's window, settles its chunk's windows and hands the window on; works
-// out its codes and their total length; waits for its predecessor's end position, hands its own on;
-// and packs its codes.  The codes go into a staging ring shared by the workgroup at their absolute bit
+// the waves side by side.  The window: a chunk without a point that violates the window in force
+// leaves it unchanged, so all chunks of a round test themselves against it at once, and only the
+// chunks that do change it take turns (see the loop in GTSC_COOP_ROUND).  The bit position: every
+// wave adds up the code lengths of the chunks before its own.  Barriers separate the steps.  The
+// codes go into a staging ring shared by the workgroup at their absolute bit
 // positions; after each round the words the round has completed leave for HBM.
 // ------------------------------------------------------------------------
 // LDS words that waves of a workgroup exchange: plain accesses the compiler may neither merge nor move
 // every LDS access this wave has made so far has been carried out
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-constexpr uint32_t COOP_WAVES = 16;        // measured on a lone 100,000-point block: 4 waves 0.63 ms, 8 0.49, 16 0.43 (one wave: 0.94)
+constexpr uint32_t COOP_WAVES = 16;
 constexpr uint32_t COOP_STAGE_WORDS = COOP_WAVES * 128;   // a round's codes (64 x 114 bits = 114 words per chunk at most) and the word before them
 
 struct CoopLds {
     uint64_t stage[COOP_STAGE_WORDS];   // image word i lives in stage[i % COOP_STAGE_WORDS] until it is written out
-    // Two mailboxes, one 64-bit word each so that a single read tells whether it is meant for the reader:
-    uint64_t win;   // chunk number << 32 | trailing zeros << 16 | leading zeros: the value window where that chunk begins
-    uint64_t pos;   // chunk number << 38 | the bit position where that chunk's codes begin (2^31 points of 114 bits fit 38 bits,
-                    // their 2^25 chunks the 26 above)
+    uint32_t lead, trail;               // the value window after the chunks settled so far
+    uint32_t flags[2];                  // bit w: wave w's chunk has a point that does not fit the window (two words taking turns)
+    uint32_t totals[COOP_WAVES];        // bits of each wave's chunk in this round
 };
-constexpr uint32_t COOP_POS_BITS = 38;
-constexpr uint64_t COOP_POS_MASK = (1ull << COOP_POS_BITS) - 1;
 
-__device__ __forceinline__ uint64_t lds_peek64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_poke64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint64_t uniform64(uint64_t x)
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// all waves of the workgroup have carried out their LDS accesses up to here (no wait for global memory: the
+// next rounds' loads stay in flight)
+__device__ __forceinline__ void coop_barrier()
 {
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |
-           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    lds_drain();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 template <int FMT>
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void encode_block_coop_kernel(Enco
     const uint64_t np64 = a.pts.size(s);
     if (np64 < a.long_threshold) return;   // the lane-per-series kernel's (the whole workgroup leaves together)
     for (uint32_t i = tid; i < COOP_STAGE_WORDS; i += 64 * COOP_WAVES) L.stage[i] = 0;
-    if (tid == 0) { L.win = NO_WINDOW; L.pos = 64; }   // chunk 0: no window yet, the header word before it
+    if (tid == 0) { L.lead = NO_WINDOW; L.trail = 0; L.flags[0] = 0; L.flags[1] = 0; }
     __syncthreads();
 
     const uint64_t p0 = a.pts.begin(s);
@@ -412,34 +413,58 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void encode_block_coop_kernel(Enco
         GTSC_COOP_LOAD(2, tC, vC, pC1, pC2, qC)
     }
     uint64_t flushed = 1;   // image words written out so far (every thread keeps count)
+    uint64_t base = 64;     // bit position where the next round's codes begin (likewise)
+    uint32_t turn = 0;      // which of the two flag words is in use
     unsigned long long* const st = reinterpret_cast<unsigned long long*>(L.stage);
 
 #define GTSC_COOP_ROUND(R, T_, V_, P1_, P2_, Q_)                                               \
     {                                                                                          \
         const uint32_t c_ = (uint32_t)(R) * COOP_WAVES + wave;                                 \
-        if (c_ < nchunks) {                                                                    \
+        const bool have_ = c_ < nchunks;                                                       \
+        PointPrep p_{};                                                                        \
+        if (have_) {                                                                           \
             const int32_t i0_ = (int32_t)(c_ * 64u) - (int32_t)phase;                          \
             const uint64_t t1_ = lane_shift_up(T_, P1_);                                       \
             const uint64_t t2_ = lane_shift_up(t1_, P2_);                                      \
             const uint64_t v1_ = lane_shift_up(V_, Q_);                                        \
-            const PointPrep p_ = prepare_point<FMT>(T_, V_, t1_, t2_, v1_, i0_ + (int32_t)lane, np, bts); \
-            /* the window chain: the predecessor's hand-over, this chunk's windows, on to the successor */ \
-            uint64_t m_;                                                                       \
-            do { m_ = uniform64(lds_peek64(&L.win)); } while ((uint32_t)(m_ >> 32) != c_);     \
-            uint32_t lead_ = (uint32_t)m_ & 0xFFFFu, trail_ = ((uint32_t)m_ >> 16) & 0xFFFFu;  \
-            uint32_t wl_, wt_; bool fresh_;                                                    \
-            resolve_window(p_.nz, p_.lz, p_.tz, lane, lead_, trail_, wl_, wt_, fresh_);        \
-            if (lane == 0) lds_poke64(&L.win, ((uint64_t)(c_ + 1u) << 32) | (trail_ << 16) | lead_); \
-            /* side by side again: codes and their lengths */                                  \
-            const LaneCode code_ = point_code<FMT>(p_, wl_, wt_, fresh_, bts);                 \
-            const uint32_t len_ = code_.hlen + code_.plen;                                     \
-            const uint32_t incl_ = wave_inclusive_sum(len_);                                   \
-            const uint32_t total_ = read_lane(incl_, 63);                                      \
-            /* the position chain */                                                           \
-            uint64_t q_;                                                                       \
-            do { q_ = uniform64(lds_peek64(&L.pos)); } while ((uint32_t)(q_ >> COOP_POS_BITS) != c_);     \
-            const uint64_t pos_ = q_ & COOP_POS_MASK;                                          \
-            if (lane == 0) lds_poke64(&L.pos, ((uint64_t)(c_ + 1u) << COOP_POS_BITS) | (pos_ + total_));  \
+            p_ = prepare_point<FMT>(T_, V_, t1_, t2_, v1_, i0_ + (int32_t)lane, np, bts);      \
+        }                                                                                      \
+        /* ---- windows.  A chunk none of whose points violates the window in force leaves it as it is, so   \
+           all chunks test themselves against it side by side; the first one that has a violator settles      \
+           its points serially (resolve_window) and publishes the window it ends with, the chunks after it    \
+           test again -- one turn of this loop per chunk that changes the window. */            \
+        uint32_t lead_ = lds_peek(&L.lead), trail_ = lds_peek(&L.trail);                       \
+        uint32_t wl_ = lead_, wt_ = trail_; bool fresh_ = false;                               \
+        if (have_ && any_lane(p_.nz && !(p_.lz >= lead_ && p_.tz >= trail_)) && lane == 0) atomicOr(&L.flags[turn & 1u], 1u << wave); \
+        coop_barrier();                                                                        \
+        for (;;) {                                                                             \
+            const uint32_t f_ = lds_peek(&L.flags[turn & 1u]);                                 \
+            if (f_ == 0) break;                                                                \
+            const uint32_t first_ = (uint32_t)__builtin_ctz(f_);                               \
+            if (wave == first_) {                                                              \
+                resolve_window(p_.nz, p_.lz, p_.tz, lane, lead_, trail_, wl_, wt_, fresh_);    \
+                if (lane == 0) { lds_poke(&L.lead, lead_); lds_poke(&L.trail, trail_); lds_poke(&L.flags[(turn + 1u) & 1u], 0u); } \
+            }                                                                                  \
+            coop_barrier();                                                                    \
+            turn++;                                                                            \
+            if (wave > first_ && have_) {                                                      \
+                lead_ = lds_peek(&L.lead); trail_ = lds_peek(&L.trail);                        \
+                wl_ = lead_; wt_ = trail_;                                                     \
+                if (any_lane(p_.nz && !(p_.lz >= lead_ && p_.tz >= trail_)) && lane == 0) atomicOr(&L.flags[turn & 1u], 1u << wave); \
+            }                                                                                  \
+            coop_barrier();                                                                    \
+        }                                                                                      \
+        /* ---- codes and where they go: every wave adds up the lengths of the chunks before its own */ \
+        const LaneCode code_ = point_code<FMT>(p_, wl_, wt_, fresh_, bts);                     \
+        const uint32_t len_ = code_.hlen + code_.plen;                                         \
+        const uint32_t incl_ = wave_inclusive_sum(len_);                                       \
+        if (lane == 0) lds_poke(&L.totals[wave], have_ ? read_lane(incl_, 63) : 0u);           \
+        coop_barrier();                                                                        \
+        const uint32_t tot_ = lane < COOP_WAVES ? __hip_atomic_load(&L.totals[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u; \
+        const uint32_t run_ = wave_inclusive_sum(tot_);                                        \
+        const uint64_t pos_ = base + (wave ? read_lane(run_, wave - 1u) : 0u);                 \
+        base += read_lane(run_, COOP_WAVES - 1u);                                              \
+        if (have_) {                                                                           \
             /* the codes into the ring: 128 bits left-aligned, shifted to their place, three words at most */ \
             const uint64_t at_ = pos_ + incl_ - len_;                                          \
             const uint32_t w0_ = (uint32_t)(at_ >> 6), sh_ = (uint32_t)at_ & 63u;              \
@@ -454,11 +479,10 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void encode_block_coop_kernel(Enco
             if (x1_) atomicOr(st + ((w0_ + 1) & (COOP_STAGE_WORDS - 1)), (unsigned long long)x1_); \
             if (x2_) atomicOr(st + ((w0_ + 2) & (COOP_STAGE_WORDS - 1)), (unsigned long long)x2_); \
         }                                                                                      \
-        /* the round is packed: its whole words leave (the mailbox holds where it ended) */    \
-        lds_drain();                                                                           \
-        __builtin_amdgcn_s_barrier();                                                          \
+        /* ---- the round is packed: its whole words leave */                                  \
+        coop_barrier();                                                                        \
         {                                                                                      \
-            const uint64_t e_ = (uniform64(lds_peek64(&L.pos)) & COOP_POS_MASK) >> 6;           \
+            const uint64_t e_ = base >> 6;                                                     \
             for (uint64_t w_ = flushed + tid; w_ < e_; w_ += 64 * COOP_WAVES) {                \
                 const uint64_t x_ = L.stage[w_ & (COOP_STAGE_WORDS - 1)];                      \
                 L.stage[w_ & (COOP_STAGE_WORDS - 1)] = 0;                                      \
@@ -466,8 +490,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void encode_block_coop_kernel(Enco
             }                                                                                  \
             flushed = e_;                                                                      \
         }                                                                                      \
-        lds_drain();                                                                           \
-        __builtin_amdgcn_s_barrier();                                                          \
+        coop_barrier();                                                                        \
     }
     for (uint32_t r = 0; r < nrounds; r += 3) {
         GTSC_COOP_ROUND(r, tA, vA, pA1, pA2, qA)
@@ -481,7 +504,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void encode_block_coop_kernel(Enco
 #undef GTSC_COOP_LOAD
     if (wave != 0) return;
     // ---- wave 0: close marker, the partial word and the zero word(s) of getLongArray()
-    uint64_t nbits = uniform64(lds_peek64(&L.pos)) & COOP_POS_MASK;
+    uint64_t nbits = base;
     if (!a.no_close) {
         // close(): '1111' + 32 ones + '0' (G/GorillaCompressor.java:84-89)
         if (lane == 0) {
@@ -935,8 +958,11 @@ __global__ __launch_bounds__(256) void count_long_kernel(uint64_t nseries, Layou
 hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream)
 {
     if (a.nseries == 0) return hipSuccess;
-    // so few blocks that a wave each would leave most SIMDs empty: a workgroup of sixteen waves each
-    static const uint64_t coop_max = [] { const char* e = getenv("GTSC_COOP_MAX"); return e ? strtoull(e, nullptr, 10) : 256ull; }();
+    // So few blocks that a wave each would leave most SIMDs empty: a workgroup of sixteen waves each.  One such
+    // workgroup keeps a compute unit busy, so the form pays up to about one and a half blocks per unit (a lone
+    // 100,000-point block: 0.25 ms against 0.95; 1,024 of them: 1.0 ms either way; 7,200-point blocks break even
+    // at about 400).
+    static const uint64_t coop_max = [] { const char* e = getenv("GTSC_COOP_MAX"); return e ? strtoull(e, nullptr, 10) : 384ull; }();
     if (a.nseries <= coop_max) {
         if (format == FMT_V2) hipLaunchKernelGGL(encode_block_coop_kernel<FMT_V2>, dim3((uint32_t)a.nseries), dim3(64 * COOP_WAVES), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_block_coop_kernel<FMT_V1>, dim3((uint32_t)a.nseries), dim3(64 * COOP_WAVES), 0, stream, a);

@@ -608,7 +608,7 @@ def test_decode_ring_choice_is_explicit(ctx):
 
 def test_wave_per_block_kernels_forced_in_their_own_process():
     """The wave-per-block kernels normally take blocks of 1,024 points and more (the decompressor only in
-    batches of few such blocks; the compressor's workgroup-per-block form batches of up to 256 blocks).  GTSC_LONG_POINTS=0 sends every block to them, whatever its length, and
+    batches of few such blocks; the compressor's workgroup-per-block form batches of up to 384 blocks).  GTSC_LONG_POINTS=0 sends every block to them, whatever its length, and
     GTSC_LONG_DECODE_MAX lifts the batch limit; both are read once per process, so a child process runs
     the randomised sweep and the parity tests that hold the odd cases (benchmark shapes incl. the 100,000-point
     blocks and skewed lengths, garbage and damaged images, quirks, zero timestamps, slot overflow, capacities)."""
@@ -620,7 +620,7 @@ def test_wave_per_block_kernels_forced_in_their_own_process():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "8", "9000"], env=env,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
-    # batches of up to 256 blocks are compressed by a workgroup of waves per block; GTSC_COOP_MAX=0 leaves
+    # batches of up to 384 blocks are compressed by a workgroup of waves per block; GTSC_COOP_MAX=0 leaves
     # them to the wave-per-block kernel as well
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "5", "7000"], env=dict(env, GTSC_COOP_MAX="0"),
                        capture_output=True, text=True, timeout=170)
