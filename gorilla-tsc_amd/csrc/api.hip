@@ -282,7 +282,7 @@ int gtsc_sync(gtsc_ctx* c)
         const uint64_t steps = counts[2] & 0xFFFFFFFFull, found = counts[2] >> 32;
         if (steps) {
             const uint64_t m = 1024 * found / steps;
-            c->long_blocks_max = m < 2048 ? 2048 : m > 16384 ? 16384 : m;
+            c->long_blocks_max = m < 2048 ? 2048 : m > 20480 ? 20480 : m;
         }
     }
     if (f & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", f);

@@ -1245,12 +1245,13 @@ static bool deep_ring_pays(uint32_t waves)
 // not until every SIMD has a wave (it is the time one lane needs for its series, 0.4 us per 1,000
 // points).  The break-even count goes with the points the kernel finds per step -- about a thousand
 // blocks per point -- so the caller passes a figure made from what the kernel reported about the
-// batches before (DecodeArgs::stats[2]); without one, 12,288.
+// batches before (DecodeArgs::stats[2]); without one, 20,480 -- the kernel then runs and reports, and a
+// context whose streams it handles badly pays for that once.
 static uint64_t long_decode_max(const DecodeArgs& a)
 {
     static const char* const e = getenv("GTSC_LONG_DECODE_MAX");
     static const uint64_t forced = e ? strtoull(e, nullptr, 10) : 0;
-    return e ? forced : a.long_blocks_max ? a.long_blocks_max : 12288ull;
+    return e ? forced : a.long_blocks_max ? a.long_blocks_max : 20480ull;
 }
 
 hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
