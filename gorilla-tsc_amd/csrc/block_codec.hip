@@ -330,19 +330,15 @@ __global__ __launch_bounds__(64) void encode_block_kernel(EncodeArgs a, uint32_t
 
 // ------------------------------------------------------------------------
 // Cooperative form of the compressor for batches of so few blocks that a wave per block leaves the
-// machine empty: a workgroup of COOP_WAVES waves per block (all on one compute unit: the waves talk through LDS).  Wave w of round r takes chunk
-// r * COOP_WAVES + w (64 points).  Everything but the window and the bit position is worked out by
-// the waves side by side.  The window: a chunk without a point that violates the window in force
-// leaves it unchanged, so all chunks of a round test themselves against it at once, and only the
-// chunks that do change it take turns (see the loop in GTSC_COOP_ROUND).  The bit position: every
-// wave adds up the code lengths of the chunks before its own.  Barriers separate the steps.  The
-// codes go into a staging ring shared by the workgroup at their absolute bit
-// positions; after each round the words the round has completed leave for HBM.
+// machine empty: a workgroup of COOP_WAVES waves per block, all on one compute unit (the waves talk
+// through LDS).  Wave w of round r takes chunk r * COOP_WAVES + w (64 points).  Everything but the
+// window and the bit position is worked out by the waves side by side.  The window: a chunk without
+// a point that violates the window in force leaves it unchanged, so all chunks of a round test
+// themselves against it at once, and only the chunks that do change it take turns (see the loop in
+// GTSC_COOP_ROUND).  The bit position: every wave adds up the code lengths of the chunks before its
+// own.  Barriers separate the steps.  The codes go into a staging ring shared by the workgroup at
+// their absolute bit positions; after each round the words the round has completed leave for HBM.
 // ------------------------------------------------------------------------
-// LDS words that waves of a workgroup exchange: plain accesses the compiler may neither merge nor move
-// every LDS access this wave has made so far has been carried out
-__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 constexpr uint32_t COOP_WAVES = 16;
 constexpr uint32_t COOP_STAGE_WORDS = COOP_WAVES * 128;   // a round's codes (64 x 114 bits = 114 words per chunk at most) and the word before them
 
@@ -353,13 +349,18 @@ struct CoopLds {
     uint32_t totals[COOP_WAVES];        // bits of each wave's chunk in this round
 };
 
-__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+// LDS words that the waves of a workgroup exchange: accesses the compiler may neither merge nor move
+// (the value read is the same in every lane and comes back as a scalar)
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
 __device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// all waves of the workgroup have carried out their LDS accesses up to here (no wait for global memory: the
-// next rounds' loads stay in flight)
+// All waves of the workgroup have carried out their LDS accesses up to here.  (Not __syncthreads(): that
+// would also wait for global memory, and the next rounds' loads are meant to stay in flight.)
 __device__ __forceinline__ void coop_barrier()
 {
-    lds_drain();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
