@@ -705,13 +705,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     GTSC_TOPUP_NEXT()
 #define GTSC_TOPUP_LAND()                                                                      \
     {                                                                                          \
-        GTSC_RING_STORE(tq, tback, filled)                                                     \
-        if constexpr (TOPUP == 4) GTSC_RING_STORE(tq2, tback2, filled + 2)                     \
-        filled += TOPUP;                                                                       \
+        bool plain_ = false;                                                                   \
+        if constexpr (TOPUP == 4) plain_ = !any_lane(filled + 8u > ssz);                       \
+        if (plain_) {                                                                          \
+            /* no landing lane is within two top-ups of its slot's end: whole pairs now and next time */ \
+            asm volatile("" : "+v"(tq), "+v"(tq2));                                            \
+            const uint32_t sl = filled & (IN_RING_WORDS - 1);                                  \
+            const uint64_t x0 = lo64(tq), x1 = hi64(tq);                                       \
+            my_ring[sl] = x0; my_ring[sl + 1] = x1; my_ring[sl + 2] = lo64(tq2); my_ring[sl + 3] = hi64(tq2); \
+            if (sl == 0) { my_ring[IN_RING_WORDS] = x0; my_ring[IN_RING_WORDS + 1] = x1; }     \
+            filled += 4;                                                                       \
+            tsrc += 4; tsrc2 += 4;                                                             \
+        } else {                                                                               \
+            GTSC_RING_STORE(tq, tback, filled)                                                 \
+            if constexpr (TOPUP == 4) GTSC_RING_STORE(tq2, tback2, filled + 2)                 \
+            filled += TOPUP;                                                                   \
+            GTSC_TOPUP_NEXT()                                                                  \
+        }                                                                                      \
         guard = filled >= nw ? nw : filled - 2;                                                \
         limit = (filled >= nw || !active) ? IN_NEVER : (filled > IN_RING_LOW ? filled - IN_RING_LOW : 0u);                   \
         pend = 0;                                                                              \
-        GTSC_TOPUP_NEXT()                                                                      \
     }
 #define GTSC_TOPUP_ISSUE() /* lanes with widx >= limit: filled < nw <= ssz */                  \
     {                                                                                          \
