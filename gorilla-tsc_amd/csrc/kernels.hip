@@ -868,9 +868,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             }
             GTSC_POINT(1)
             if constexpr (RING == 8) {
-                if (pend) GTSC_TOPUP_LAND()
-                const bool low = d.widx >= limit;
-                if (low) GTSC_TOPUP_ISSUE()
+                // sparse streams: a look at the rings every second pair is enough (16 bytes last 25 points of a
+                // gauge; a lane that does run short is tended to where it happens, see GTSC_POINT)
+                if (k2 & 1u) {
+                    if (pend) GTSC_TOPUP_LAND()
+                    const bool low = d.widx >= limit;
+                    if (low) GTSC_TOPUP_ISSUE()
+                }
             } else {
                 // requests are made at every second check only, and land at the next such check: what the wave
                 // waits for then is two checks old in every lane.  In between only a lane about to run out lands.
@@ -1234,7 +1238,7 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
 // Dense streams decode faster from 16-word rings, but a compute unit holds 7 such waves against 8 with
 // 8-word rings.  When a batch is only a few rounds of waves (long series: a wave lives for
 // milliseconds), what counts is how the waves fill the rounds: 4,096 waves are two full rounds of 8 per
-// unit but two and a third of 7.  The model: a full round costs 1 (0.72 with 16-word rings, measured on
+// unit but two and a third of 7.  The model: a full round costs 1 (0.62 with 16-word rings, measured on
 // dense streams), the last, partly filled one 0.55 + 0.45 x its fill (fewer waves per unit run faster).
 static bool deep_ring_pays(uint32_t waves)
 {
@@ -1249,7 +1253,7 @@ static bool deep_ring_pays(uint32_t waves)
         const uint32_t rem = waves % slots;
         return ((double)(waves / slots) + (rem ? 0.55 + 0.45 * (double)rem / (double)slots : 0.0)) * round;
     };
-    return cost(7u * units, 0.72) <= cost(8u * units, 1.0);
+    return cost(7u * units, 0.62) <= cost(8u * units, 1.0);
 }
 
 // Up to how many long blocks a batch is decoded by the wave-per-block kernel.  That kernel's time grows
