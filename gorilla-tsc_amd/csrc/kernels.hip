@@ -20,7 +20,7 @@
 //   -DGTSC_ABLATE=n     leaves one cost out to see what it is worth (1/3: encoder arithmetic, 4: decoder
 //                       stores, 5: decoder tile writes, 6: decoder ring reads, 7: both, 8: the encoder's stores
 //                       of compressed words before the last copy); results are wrong
-//   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy
+//   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy (-DGTSC_DEC_LDS_PAD=n: the decoder's)
 //   -DGTSC_POISON=x     the decoder's input rings start out filled with x (nothing may depend on slots never written)
 #ifndef GTSC_ABLATE
 #define GTSC_ABLATE 0
@@ -219,6 +219,9 @@ constexpr uint32_t RING_TRIGGER = RING_WORDS - 4;
 
 #ifndef GTSC_LAND_LOW
 #define GTSC_LAND_LOW 5u
+#endif
+#ifndef GTSC_DEC_LDS_PAD
+#define GTSC_DEC_LDS_PAD 0
 #endif
 #ifndef GTSC_LDS_PAD
 #define GTSC_LDS_PAD 0
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     constexpr uint32_t OFF_TS = TILE_BYTES;
     constexpr uint32_t OFF_RING = OFF_TS + DEC_TS_TILE_BYTES;
     constexpr uint32_t OFF_ROWS = OFF_RING + 64 * IN_RING_ROW_BYTES;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ROWS + 64 * sizeof(DecRow)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ROWS + 64 * sizeof(DecRow) + GTSC_DEC_LDS_PAD];
     uint8_t* const tile_val = lds;
     uint8_t* const tile_ts = lds + OFF_TS;
     uint8_t* const ring = lds + OFF_RING;
