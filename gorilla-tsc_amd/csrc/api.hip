@@ -369,7 +369,7 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
                  out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, c->forced_ring == 16 ? 2u : (c->deep_ring ? 1u : 0u),
-                 reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count, c->long_blocks_max};
+                 reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count, c->long_blocks_max, 0u};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -676,7 +676,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
                      st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
                      (c->forced_ring ? (c->forced_ring == 16 ? 2u : 0u) : (nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u)) /* the host form knows the density */,
                      nullptr,
-                     ~0ull, nullptr, 0, c->d_long_count + 1, c->long_blocks_max};
+                     ~0ull, nullptr, 0, c->d_long_count + 1, c->long_blocks_max, 0u};
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, c->work, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, c->work));
         HIP_TRY(hipEventRecord(st.coded, c->work));

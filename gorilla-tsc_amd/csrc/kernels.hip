@@ -588,11 +588,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     constexpr uint32_t OFF_TS = TILE_BYTES;
     constexpr uint32_t OFF_RING = OFF_TS + DEC_TS_TILE_BYTES;
     constexpr uint32_t OFF_ROWS = OFF_RING + 64 * IN_RING_ROW_BYTES;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_ROWS + 64 * sizeof(DecRow) + GTSC_DEC_LDS_PAD];
+    constexpr uint32_t OFF_RUNS = OFF_ROWS + 64 * sizeof(DecRow);
+    constexpr bool RUN_SKIP = RING == 8;              // the form sparse streams take: see the event loop below
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_RUNS + (RUN_SKIP ? 64 * sizeof(U4) : 0) + GTSC_DEC_LDS_PAD];
     uint8_t* const tile_val = lds;
     uint8_t* const tile_ts = lds + OFF_TS;
     uint8_t* const ring = lds + OFF_RING;
     DecRow* const rows = reinterpret_cast<DecRow*>(lds + OFF_ROWS);
+    U4* const runs = reinterpret_cast<U4*>(lds + OFF_RUNS);  // RUN_SKIP only: {timestamp before the chunk (low half), delta, slots written, -}
 
 #ifdef GTSC_STAMP
     const uint64_t tk_entry = __builtin_amdgcn_s_memtime();
@@ -854,13 +857,113 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             GTSC_WINDOW_READ()                                                                 \
         }                                                                                      \
     }
+    // Run skipping (8-word form).  Most points of a sparse stream are the two bits '00': regular cadence,
+    // value unchanged.  Walking the 16 slots of a chunk in lock step spends a full parse on each of them in
+    // every lane.  Here the lanes go through a chunk at their own pace instead: in one step a lane jumps
+    // over the run of '00' points at its position (a count of leading zeros) and parses the one point after
+    // it, so a chunk takes as many steps as its busiest row has changed values (5 or 6 of 16 when one value
+    // in ten changes).  The lane writes only the values that changed to its tile row, marks their slots, and
+    // leaves (timestamp before the chunk, delta) for the flush, which fills in the rest: the latest marked
+    // slot at or before each slot gives its value, the slot number times the delta its timestamp.
+    // A chunk qualifies when all 64 rows are under way, past their first point, with 16 slots to fill and a
+    // delta of 0..2^32-1.  Whatever is not ordinary in any lane (a timestamp code other than '0', end of
+    // stream, a window never defined, words not yet in the ring, a timestamp whose high half moves) drops
+    // the attempt: the lanes go back to where the chunk began and take the lock-step loop, which knows all
+    // of that; nothing the attempt did needs undoing (it lands no top-ups and the tile is rewritten).
+    uint32_t run_wait = 0;     // wave-uniform: chunks to sit out before the next attempt
+#ifdef GTSC_RUNSTAT
+    uint32_t rs_try = 0, rs_ok = 0, rs_steps = 0, rs_chunks = 0; uint64_t rs_why = 0;
+#endif
+    uint32_t run_backoff = 1;  // doubles with every failed attempt
+    const uint32_t swz = ((lane >> 1) & (PIECES - 1)) << 1;  // slot j of this lane's tile row sits at (j ^ swz) * 8
+    uint8_t* const my_vals = tile_val + lane * ROW_BYTES;
     for (uint32_t c = 0; active_m != 0; c++) {
         ts_ref = (uint32_t)(d.stored_ts >> 32);
         n0 = n;
         dmask = 0;
         if (dense) dense--;
+        bool skipped = false;      // wave-uniform: the chunk was decoded by run skipping
+#ifdef GTSC_RUNSTAT
+        rs_chunks++;
+        if (c != 0 && run_wait == 0) rs_why |= (dense != 0 ? 1u : 0u) | (slow_m != 0 ? 2u : 0u) | (active_m != ~0ull ? 4u : 0u) | (lanes(n + DCH > cap) ? 8u : 0u) | (lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u) ? 16u : 0u);
+#endif
+        uint32_t run_slots = 1u;   // slots of the chunk whose values the lane wrote (slot 0: the value before the chunk)
+        const uint32_t run_ts = (uint32_t)d.stored_ts, run_delta = (uint32_t)d.stored_delta;
+        if constexpr (RUN_SKIP) {
+            if (run_wait) {
+                run_wait--;
+            } else if (a.run_skip && c != 0 && dense == 0 && slow_m == 0 && active_m == ~0ull &&
+                       (lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) == 0) {
+                const WindowDecoder<FMT> d_at = d;
+                const uint64_t w0_at = w0, w1_at = w1, w2_at = w2;
+                const uint64_t delta = (uint64_t)d.stored_delta;
+                *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
+                uint32_t k = 0;       // slots of the chunk the lane has behind it
+                uint32_t steps = 0;
+                uint64_t bad_m = 0;
+                while (any_lane(k < DCH)) {
+                    // the run: each '00' is a point; a lane that is through the chunk has no room and stays put
+                    const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);
+                    const uint32_t zeros = (uint32_t)__clz((int)(uint32_t)(hi >> 32));  // 32 when there is no one
+                    const uint32_t room = DCH - k;
+                    const uint32_t m = (zeros >> 1) < room ? (zeros >> 1) : room;
+                    const uint32_t o = d.off + 2u * m;  // <= 63 + 32
+                    // the point after the run, parsed from the words at hand: (w0,w1,w2), or (w1,w2) when
+                    // the run crossed into w1 -- a payload that needs the word after w2 then drops the attempt
+                    WindowDecoder<FMT> t = d;
+                    t.widx = d.widx + (o >> 6);
+                    t.off = o & 63u;
+                    const uint64_t u0 = o >= 64u ? w1 : w0, u1 = o >= 64u ? w2 : w1;
+                    const uint64_t hi2 = WindowDecoder<FMT>::window(u0, u1, t.off);
+                    const uint64_t u2 = w2;
+                    const uint32_t off2 = t.off;
+                    auto lo2 = [u1, u2, off2] { return WindowDecoder<FMT>::window(u1, u2, off2); };
+                    const typename WindowDecoder<FMT>::Parsed p = t.template parse<true>(hi2, lo2);
+                    const uint64_t more_m = lanes(m < room);  // lanes with a point to parse
+                    bad_m |= more_m & (lanes((int64_t)hi2 < 0) | (lanes(p.changed) & lanes(p.nbits == 0)) |
+                                       (lanes(o >= 64u) & lanes(p.o3 - off2 > 64u)));
+                    const bool more = m < room;
+                    const uint32_t cnt = m + (more ? 1u : 0u);
+                    t.stored_ts = d.stored_ts + (uint64_t)cnt * delta;
+                    if (more) {
+                        t.nbits = p.nbits;
+                        t.trail = p.trail;
+                        t.val = d.val ^ (p.bits << ((uint32_t)p.trail & 63u));
+                        t.advance(p.o3);
+                        *reinterpret_cast<uint64_t*>(my_vals + (((k + m) ^ swz) << 3)) = t.val;
+                        run_slots |= 1u << (k + m);
+                    }
+                    bad_m |= lanes(t.widx >= guard);
+                    d = t;
+                    k += cnt;
+                    n += cnt;
+                    steps++;
+                    GTSC_WINDOW_READ()
+                    if (bad_m) break;
+                }
+                bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref);
+#ifdef GTSC_RUNSTAT
+                rs_try++; rs_steps += steps; if (bad_m == 0) rs_ok++;
+#endif
+                if (bad_m == 0) {
+                    skipped = true;
+                    run_backoff = 1;
+                    if (steps > 12) run_wait = 8;  // nearly every value changes: nothing to skip
+                    if (pend) GTSC_TOPUP_LAND()
+                    const bool low = d.widx >= limit;
+                    if (low) GTSC_TOPUP_ISSUE()
+                } else {
+                    d = d_at;
+                    n = n0;
+                    w0 = w0_at; w1 = w1_at; w2 = w2_at;
+                    run_wait = run_backoff;
+                    run_backoff = run_backoff < 64 ? run_backoff * 2 : 64;
+                }
+            }
+        }
         // the eight pairs of a chunk unrolled: tile addresses and the which-check-is-it tests become constants
         // (3 % on gauges, 5 % on long gauge series; the code still fits the instruction cache)
+        if (!skipped) {
 #pragma unroll
         for (uint32_t k2 = 0; k2 < DCH / 2; k2++) {
             const uint32_t ad = tile_addr(lane, k2);
@@ -898,6 +1001,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 }
             }
         }
+        }  // !skipped
 #if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
         if (active && c * DCH >= cap) { active = false; nfin = n; }
         active_m = lanes(active);
@@ -911,13 +1015,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         const uint32_t hi_rel = end <= c * DCH ? 0u : (end - c * DCH < DCH ? end - c * DCH : DCH);
         const uint32_t info = lo_rel | (hi_rel << 8) | (dmask << 16);
         *reinterpret_cast<uint2*>(&rows[lane].info) = make_uint2(info, ts_ref);
+        if constexpr (RUN_SKIP) {
+            if (skipped) runs[lane] = U4{run_ts, run_delta, run_slots, 0u};
+        }
         wave_sync();
         const uint32_t j0 = 2 * piece;
         const uint32_t v0 = c * DCH + j0;
         U4 ri[PASSES];
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
-        if (all_lanes(info == DEC_ROW_FULL)) {
+        if (RUN_SKIP && skipped) {
+            // a chunk decoded by run skipping (every row has all 16 slots): a slot's value is the one written at
+            // the latest marked slot at or before it, its timestamp the one before the chunk plus (slot + 1) deltas
+            uint64_t q0[PASSES], q1[PASSES];
+            uint32_t t0[PASSES], t1[PASSES];
+            const uint32_t upto0 = (2u << j0) - 1u, upto1 = (4u << j0) - 1u;  // slots 0..j0, 0..j0+1
+#pragma unroll
+            for (uint32_t i = 0; i < PASSES; i++) {
+                const uint32_t r = lrow + i * ROWS_PER_PASS;
+                const U4 rr = runs[r];
+                const uint32_t rswz = ((r >> 1) & (PIECES - 1)) << 1;
+                const uint32_t s0 = 31u - (uint32_t)__clz((int)(rr.z & upto0)), s1 = 31u - (uint32_t)__clz((int)(rr.z & upto1));
+                q0[i] = *reinterpret_cast<const uint64_t*>(tile_val + r * ROW_BYTES + ((s0 ^ rswz) << 3));
+                q1[i] = *reinterpret_cast<const uint64_t*>(tile_val + r * ROW_BYTES + ((s1 ^ rswz) << 3));
+                t0[i] = rr.x + (j0 + 1u) * rr.y;
+                t1[i] = t0[i] + rr.y;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < PASSES; i++) {
+                const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
+                const U4 t = {t0[i], ri[i].w, t1[i], ri[i].w};
+                const U4 v = {(uint32_t)q0[i], (uint32_t)(q0[i] >> 32), (uint32_t)q1[i], (uint32_t)(q1[i] >> 32)};
+#if GTSC_ABLATE == 4
+                asm volatile("" ::"v"(t), "v"(v), "v"(idx));
+#else
+#ifdef GTSC_PLAIN_STORES
+                *reinterpret_cast<U4*>(a.ts + idx) = t;
+                *reinterpret_cast<U4a8*>(a.val + idx) = v;
+#else
+                __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
+                __builtin_nontemporal_store(v, reinterpret_cast<U4a8*>(a.val + idx));
+#endif
+#endif
+            }
+        } else if (all_lanes(info == DEC_ROW_FULL)) {
             // every row has all 16 slots of this chunk: read everything, then store everything
             uint2 qt[PASSES];
             U4 qv[PASSES];
@@ -935,8 +1076,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 asm volatile("" ::"v"(t), "v"(qv[i]), "v"(idx));
 #else
                 // whole aligned lines that nothing reads again soon: streaming stores
+#ifdef GTSC_PLAIN_STORES
+                *reinterpret_cast<U4*>(a.ts + idx) = t;
+                *reinterpret_cast<U4a8*>(a.val + idx) = qv[i];
+#else
                 __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
                 __builtin_nontemporal_store(qv[i], reinterpret_cast<U4a8*>(a.val + idx));
+#endif
 #endif
             }
         } else {
@@ -971,6 +1117,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         wave_sync();
         GTSC_TICK(tk_flush)
     }
+#ifdef GTSC_RUNSTAT
+    if (blockIdx.x == 1000 && lane == 0) printf("runstat: chunks %u tried %u ok %u steps %u why %llx\n", rs_chunks, rs_try, rs_ok, rs_steps, (unsigned long long)rs_why);
+#endif
 #undef GTSC_TOPUP_LAND
 #undef GTSC_TOPUP_ISSUE
 #undef GTSC_TOPUP_NEXT
@@ -1310,6 +1459,8 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
         static const int forced = [] { const char* e = getenv("GTSC_RING"); return e ? atoi(e) : 0; }();  // tests: 8 or 16
+        static const bool no_run_skip = [] { const char* e = getenv("GTSC_RUN_SKIP"); return e && !strcmp(e, "0"); }();  // tests
+        g.run_skip = no_run_skip ? 0u : 1u;
         bool deep = forced ? forced == 16 : a.deep_ring != 0;
         if (!forced && a.deep_ring == 1) deep = deep_ring_pays(blocks);
         if (format == FMT_V2) {

@@ -53,6 +53,7 @@ struct DecodeArgs {
     uint64_t long_max_series;
     uint64_t* long_count_buf; // from the caller: one device word the launcher may use for the count (may be null)
     uint64_t long_blocks_max; // from the caller: up to how many long blocks a batch goes to the wave-per-block kernel (0: the built-in figure)
+    uint32_t run_skip;        // set by the launcher: the 8-word form may decode chunks by run skipping (see decode_tiled_kernel)
 };
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);

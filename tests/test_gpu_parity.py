@@ -575,6 +575,92 @@ def test_zero_timestamps_inside_full_chunks(ctx, gfmt, ofmt):
             assert np.array_equal(gts[a:a + n], rts[a:a + n]) and np.array_equal(gval[a:a + n], rval[a:a + n])
 
 
+def _run_skip_batch(S=256, P=200, seed=11):
+    """Gauges (one value in ten changes, regular cadence: the streams the decompressor skips runs in) with rows of
+    every kind that must drop a run-skipping attempt, or bend it, mixed into each wave of 64."""
+    rng = np.random.default_rng(seed)
+    g = synth.gauge_integer(S=S, P=P, seed=seed)
+    ts = g.ts.reshape(S, P).copy()
+    val = g.val.reshape(S, P).copy()
+    block = g.block_ts.copy()
+    step = np.arange(1, P + 1, dtype=np.int64)
+    for w in range(0, S, 64):
+        block[w + 3] = (350 << 32) - 60000 * 100            # the high half of the timestamps moves at point 100
+        ts[w + 3] = block[w + 3] + 60000 * step
+        val[w + 5] = val[w + 5, 0]                           # a constant: nothing but runs
+        block[w + 7] = 1000                                  # timestamps below 2^32
+        ts[w + 7] = 1000 + step
+        ts[w + 9, 77:] += 5                                  # one irregular interval
+        block[w + 11] = -3000                                # negative timestamps that reach zero at point 50
+        ts[w + 11] = -3000 + 60 * step
+        block[w + 13] = 1 << 40                              # timestamps that run backwards
+        ts[w + 13] = (1 << 40) - 60000 * step
+        block[w + 15] = 0                                    # a delta of 2^33
+        ts[w + 15] = (1 << 33) * step
+        val[w + 17] = rng.integers(0, 1 << 63, size=P, dtype=np.int64).view(np.uint64)  # a dense row among sparse ones
+        val[w + 19, 60:] = rng.integers(0, 1 << 63, dtype=np.int64)                      # a long run, then all 64 bits change
+        val[w + 21, ::7] ^= np.uint64(0x8000000000000001)     # payloads of 64 bits every seventh point
+        ts[w + 23, 120] = ts[w + 23, 119]                     # a repeated timestamp (delta 0 from there)
+        ts[w + 23, 121:] = ts[w + 23, 119]
+    return synth.Batch(block, np.ascontiguousarray(ts.reshape(-1)), np.ascontiguousarray(val.reshape(-1)), g.pt_off)
+
+
+@pytest.mark.parametrize("gfmt,ofmt", FMTS)
+def test_run_skipping_decoder_matches_oracle(ctx, gfmt, ofmt):
+    """Sparse streams are decoded a run of unchanged points at a time (decode_tiled_kernel).  Whole waves of gauges
+    with the awkward rows of _run_skip_batch among them: points, counts and status as the oracle's decoder gives
+    them, with capacities at, above and below the block length, images cut short, and images of zero words."""
+    b = _run_skip_batch()
+    S, P = b.nseries, b.uniform_npoints()
+    out, off, nw, d_out, d_nw = check_encode_against_oracle(ctx, b, gfmt, ofmt, uniform=True)
+    for cap in (P, P + 3, P - 5, 16 * (P // 16)):
+        cap_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(cap)
+        gts, gval, npts, st, rc = gpu_decode(ctx, out, off, nw, cap_off, gfmt, uniform_cap=cap)
+        rts, rval, rnp, rst = O.decode_batch(out, off, nw, cap_off, fmt=ofmt, nthreads=8)
+        assert np.array_equal(st, rst) and np.array_equal(npts, rnp), cap
+        for s in range(S):
+            a, n = s * cap, int(min(npts[s], cap))
+            assert np.array_equal(gts[a:a + n], rts[a:a + n]) and np.array_equal(gval[a:a + n], rval[a:a + n]), (cap, s)
+            assert np.all(gts[a + n:a + cap] == -7) and np.all(gval[a + n:a + cap] == np.uint64(2 ** 64 - 7)), (cap, s)
+    # damaged input: images cut short anywhere, and images whose words from some point on are zero
+    # (an endless run of unchanged points as far as the bits say)
+    rng = np.random.default_rng(5)
+    cut = nw.copy()
+    some = rng.random(S) < 0.25
+    cut[some] = (cut[some] * rng.random(int(some.sum()))).astype(np.uint64)
+    zeroed = out.copy()
+    for s in np.flatnonzero(rng.random(S) < 0.25):
+        a = int(off[s]) + int(rng.integers(1, int(nw[s])))
+        zeroed[a:int(off[s + 1])] = 0
+    cap_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(P)
+    for words, in_nw in ((out, cut), (zeroed, nw), (zeroed, np.full(S, int(off[1]), dtype=np.uint64))):
+        gts, gval, npts, st, rc = gpu_decode(ctx, words, off, in_nw, cap_off, gfmt, uniform_cap=P)
+        rts, rval, rnp, rst = O.decode_batch(words, off, in_nw, cap_off, fmt=ofmt, nthreads=8)
+        assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+        for s in range(S):
+            a, n = s * P, int(min(npts[s], P))
+            assert np.array_equal(gts[a:a + n], rts[a:a + n]) and np.array_equal(gval[a:a + n], rval[a:a + n]), s
+            assert np.all(gts[a + n:a + P] == -7), s
+
+
+def test_lock_step_decoder_in_its_own_process():
+    """GTSC_RUN_SKIP=0 keeps the 8-word form of the lane-per-series decompressor on its lock-step loop for every
+    chunk (the loop that run skipping falls back to); read once per process, so a child runs the sweep and the
+    tests of sparse streams with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTSC_RUN_SKIP="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "6", "12000"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "run_skipping or zero_timestamps or high_half or garbage"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_lane_per_series_kernels_in_their_own_process():
     """The plain lane-per-series kernels (both formats) are what GTSC_KERNEL=direct selects; the choice is read
     once per process, so the sweep runs in a child process for a few seconds."""

@@ -1,0 +1,160 @@
+// Microbenchmark: the decoder's output pattern without the decoding.  A wave owns 64 rows (series) of P
+// points in two arrays (timestamps, values); step after step it writes SEG bytes of every row to both,
+// 8 lanes x 16 bytes per 128-byte line, as the decoder's chunk flush does.  Variants: bytes per row and
+// step (128, 256, 512), streaming or plain stores, and a fully sequential write of the same bytes.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef unsigned U4 __attribute__((ext_vector_type(4)));
+
+// SEG bytes per row and step; GAP: s_sleep units between steps (stands for the decoding of a chunk)
+template <int SEG, bool NT, int GAP>
+__global__ __launch_bounds__(64) void rows_kernel(char* ts, char* val, size_t row_bytes, size_t nrows, unsigned shift)
+{
+    const unsigned lane = threadIdx.x, block = blockIdx.x;
+    // rows of equal line phase per wave, the waves of a group 8 workgroups apart (one XCD)
+    const unsigned r = block & ((8u << shift) - 1u);
+    const size_t group = ((size_t)(block >> (3 + shift)) << 3) + (r & 7u);
+    const size_t row0 = (group << (6 + shift)) + (r >> 3);
+    constexpr int LPR = SEG / 16;      // lanes per row and instruction
+    constexpr int RPI = 64 / LPR;      // rows per instruction
+    const unsigned piece = lane % LPR, lrow = lane / LPR;
+    const size_t steps = row_bytes / SEG;  // whole segments only
+    for (size_t c = 0; c < steps; c++) {
+#pragma unroll
+        for (int i = 0; i < 64 / RPI; i++) {
+            const size_t row = row0 + ((size_t)(lrow + i * RPI) << shift);
+            if (row < nrows) {
+                const size_t o = row * row_bytes + c * SEG + piece * 16;
+                const U4 v = {(unsigned)row, (unsigned)c, lane, 1u};
+                if (NT) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<U4*>(ts + o));
+                    __builtin_nontemporal_store(v, reinterpret_cast<U4*>(val + o));
+                } else {
+                    *reinterpret_cast<U4*>(ts + o) = v;
+                    *reinterpret_cast<U4*>(val + o) = v;
+                }
+            }
+        }
+        if (GAP) __builtin_amdgcn_s_sleep(GAP);
+    }
+}
+
+// a wave writes BLK contiguous bytes of one array, then of the other; waves take blocks in turn
+template <int BLK, bool NT, bool TWO>
+__global__ __launch_bounds__(64) void blocks_kernel(char* ts, char* val, size_t bytes)
+{
+    const size_t nblk = bytes / BLK;
+    for (size_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+#pragma unroll 8
+        for (int o = 0; o < BLK; o += 1024) {
+            const U4 v = {(unsigned)b, (unsigned)o, 1u, 2u};
+            char* p = ts + b * BLK + o + threadIdx.x * 16;
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<U4*>(p)); else *reinterpret_cast<U4*>(p) = v;
+        }
+        if (TWO) {
+#pragma unroll 8
+            for (int o = 0; o < BLK; o += 1024) {
+                const U4 v = {(unsigned)b, (unsigned)o, 1u, 2u};
+                char* p = val + b * BLK + o + threadIdx.x * 16;
+                if (NT) __builtin_nontemporal_store(v, reinterpret_cast<U4*>(p)); else *reinterpret_cast<U4*>(p) = v;
+            }
+        }
+    }
+}
+
+// rows kernel with all timestamp stores of a step before its value stores
+template <int SEG, bool NT>
+__global__ __launch_bounds__(64) void rows_split_kernel(char* ts, char* val, size_t row_bytes, size_t nrows)
+{
+    const unsigned lane = threadIdx.x;
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    constexpr int LPR = SEG / 16, RPI = 64 / LPR;
+    const unsigned piece = lane % LPR, lrow = lane / LPR;
+    const size_t steps = row_bytes / SEG;
+    for (size_t c = 0; c < steps; c++) {
+        for (int w = 0; w < 2; w++) {
+            char* dst = w ? val : ts;
+#pragma unroll
+            for (int i = 0; i < 64 / RPI; i++) {
+                const size_t row = row0 + lrow + i * RPI;
+                if (row < nrows) {
+                    const size_t o = row * row_bytes + c * SEG + piece * 16;
+                    const U4 v = {(unsigned)row, (unsigned)c, lane, 1u};
+                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<U4*>(dst + o)); else *reinterpret_cast<U4*>(dst + o) = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void seq_kernel(char* ts, char* val, size_t bytes)
+{
+    const size_t n = bytes / 16, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const U4 v = {(unsigned)i, 0u, 1u, 2u};
+        if (NT) {
+            __builtin_nontemporal_store(v, reinterpret_cast<U4*>(ts) + i);
+            __builtin_nontemporal_store(v, reinterpret_cast<U4*>(val) + i);
+        } else {
+            reinterpret_cast<U4*>(ts)[i] = v;
+            reinterpret_cast<U4*>(val)[i] = v;
+        }
+    }
+}
+
+template <class F>
+float timeit(F f, int reps = 10)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f(); f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main(int argc, char** argv)
+{
+    const size_t nrows = 1000000, P = argc > 1 ? (size_t)atoi(argv[1]) : 128, row_bytes = P * 8;
+    const size_t bytes = nrows * row_bytes;
+    char *ts, *val;
+    CK(hipMalloc(&ts, bytes + 4096)); CK(hipMalloc(&val, bytes + 4096));
+    CK(hipMemset(ts, 0, bytes)); CK(hipMemset(val, 0, bytes));
+    const unsigned blocks = (unsigned)((nrows + 63) / 64);
+    auto rep = [&](const char* name, float ms) { printf("%-44s %.4f ms  %.0f GB/s\n", name, ms, 2.0 * bytes / ms / 1e6); };
+    printf("rows of %zu bytes, %zu rows, two arrays\n", row_bytes, nrows);
+    rep("hipMemsetAsync of both arrays", timeit([&] { CK(hipMemsetAsync(ts, 1, bytes, 0)); CK(hipMemsetAsync(val, 2, bytes, 0)); }));
+    rep("sequential, streaming, 256 x 32 blocks", timeit([&] { seq_kernel<true><<<256 * 32, 256>>>(ts, val, bytes); }));
+    rep("sequential, plain, 256 x 32 blocks", timeit([&] { seq_kernel<false><<<256 * 32, 256>>>(ts, val, bytes); }));
+    rep("sequential, plain, 256 x 4 blocks", timeit([&] { seq_kernel<false><<<256 * 4, 256>>>(ts, val, bytes); }));
+    rep("blocks of 8 KB per wave, plain, both", timeit([&] { blocks_kernel<8192, false, true><<<256 * 32, 64>>>(ts, val, bytes); }));
+    rep("blocks of 8 KB per wave, streaming, both", timeit([&] { blocks_kernel<8192, true, true><<<256 * 32, 64>>>(ts, val, bytes); }));
+    rep("blocks of 64 KB per wave, plain, both", timeit([&] { blocks_kernel<65536, false, true><<<256 * 32, 64>>>(ts, val, bytes); }));
+    rep("blocks of 64 KB per wave, streaming, both", timeit([&] { blocks_kernel<65536, true, true><<<256 * 32, 64>>>(ts, val, bytes); }));
+    rep("blocks of 64 KB, plain, both, 2048 waves", timeit([&] { blocks_kernel<65536, false, true><<<256 * 8, 64>>>(ts, val, bytes); }));
+    rep("blocks of 8 KB, plain, ts only (x2 bytes)", 2 * timeit([&] { blocks_kernel<8192, false, false><<<256 * 32, 64>>>(ts, val, bytes); }));
+    rep("rows, 128 B, plain, ts then val", timeit([&] { rows_split_kernel<128, false><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows); }));
+    rep("rows, 128 B, streaming, ts then val", timeit([&] { rows_split_kernel<128, true><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows); }));
+    rep("rows, 128 B, plain, ts then val, 32 waves/CU", timeit([&] { rows_split_kernel<128, false><<<blocks, 64>>>(ts, val, row_bytes, nrows); }));
+    rep("sequential, streaming", timeit([&] { seq_kernel<true><<<256 * 8, 256>>>(ts, val, bytes); }));
+    rep("sequential, plain", timeit([&] { seq_kernel<false><<<256 * 8, 256>>>(ts, val, bytes); }));
+    rep("rows, 128 B per step, streaming", timeit([&] { rows_kernel<128, true, 0><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 128 B per step, plain", timeit([&] { rows_kernel<128, false, 0><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 256 B per step, streaming", timeit([&] { rows_kernel<256, true, 0><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 512 B per step, streaming", timeit([&] { rows_kernel<512, true, 0><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 128 B per step, streaming, gap 8", timeit([&] { rows_kernel<128, true, 8><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 128 B per step, streaming, gap 32", timeit([&] { rows_kernel<128, true, 32><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 128 B per step, streaming, gap 64", timeit([&] { rows_kernel<128, true, 64><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 256 B per step, streaming, gap 64", timeit([&] { rows_kernel<256, true, 64><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 256 B per step, streaming, gap 127", timeit([&] { rows_kernel<256, true, 127><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    rep("rows, 128 B, streaming, phase pairs (shift 1)", timeit([&] { rows_kernel<128, true, 32><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 1); }));
+    CK(hipGetLastError());
+    return 0;
+}
