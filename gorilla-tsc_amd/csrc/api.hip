@@ -310,7 +310,7 @@ int gtsc_encode_device_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t ns
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
     EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
-                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, tables, c->dfcm_mask, 0u, ~0ull};
+                 out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, tables, c->dfcm_mask, 0u, ~0ull, 0u};
     HIP_TRY(launch_encode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -590,7 +590,7 @@ int gtsc_encode_host_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nser
         EncodeArgs a{g.ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
                      Layout{g.d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{g.d_slot_off, g.uniform_slot},
                      st.nwords.as<uint64_t>(), nullptr, c->d_flags_host, out_nbits ? st.nbits.as<uint64_t>() : nullptr,
-                     (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, nullptr, c->dfcm_mask, 0u, ~0ull};
+                     (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, nullptr, c->dfcm_mask, 0u, ~0ull, 0u};
         HIP_TRY(dfcm_prepare(c, 1 + b, g.ns, c->work, &a.dfcm_tables));
         HIP_TRY(launch_encode(a, format, c->work));
         HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), g.ns, st.coff.as<uint64_t>(), c->scan_scratch.as<uint64_t>(), c->work));

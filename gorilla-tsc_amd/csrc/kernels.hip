@@ -22,6 +22,8 @@
 //                       of compressed words before the last copy); results are wrong
 //   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy (-DGTSC_DEC_LDS_PAD=n: the decoder's)
 //   -DGTSC_POISON=x     the decoder's input rings start out filled with x (nothing may depend on slots never written)
+//   -DGTSC_RUNSTAT      one wave prints how many chunks it decoded by run skipping, in how many steps, and why not
+//   -DGTSC_PLAIN_STORES the decoder's full-chunk stores as plain instead of streaming stores
 #ifndef GTSC_ABLATE
 #define GTSC_ABLATE 0
 #endif
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #else
 #define GTSC_TICK(acc_)
 #endif
+    uint32_t run_wait = 0;  // wave-uniform: chunks to code in lock step before run skipping is tried again
     wave_sync();  // rows[] visible
     if (nchunks) GTSC_FETCH(0)
     GTSC_TICK(tk_fetch)
@@ -449,7 +452,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
             // timestamp: no guards, no first-point test, four points per step
             // (rows that ended in an earlier chunk sit the chunk out: a batch of very unequal blocks
             // keeps this loop for its long blocks)
-            if (all_lanes(idle || (interior && e.started && zbits == 0))) {
+            const bool plain_chunk = all_lanes(idle || (interior && e.started && zbits == 0));
+            if (plain_chunk && a.run_skip && run_wait == 0) {
+                // Run skipping.  Most points of a sparse stream are the two bits '00' (the interval and the value
+                // of the point before).  First the lane goes over its 16 slots with two comparisons each and
+                // marks the others; then it takes one step per marked point -- the zero bits of the run before it
+                // and the point's own codes, in one piece when they fit a word -- so a chunk costs as many
+                // full codings as its busiest row has changes (5 or 6 of 16 when one value in ten changes).
+                uint32_t marks = 0;  // bit 31 - j: the point in slot j is not '00'
+                uint32_t pt = e.pts_lo, pd = (uint32_t)e.stored_delta;
+                uint64_t pv = e.prev;
+#pragma unroll
+                for (uint32_t q = 0; q < PIECES; q += 2) {
+                    const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
+                    const U4 va = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                    const U4 vb = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q + 1));
+                    const uint32_t tj[4] = {tl.x, tl.y, tl.z, tl.w};
+                    const uint64_t vj[4] = {lo64(va), hi64(va), lo64(vb), hi64(vb)};
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        const uint32_t nd = tj[i] - pt;
+                        const bool other = (nd != pd) | (vj[i] != pv);
+                        marks |= other ? 0x80000000u >> (2 * q + i) : 0u;
+                        pt = tj[i]; pd = nd; pv = vj[i];
+                    }
+                }
+                if (idle) marks = 0;
+                uint32_t pos = 0, steps = 0;
+                const uint32_t tswz = ((lane >> 2) & 3u) << 2, vswz = ((lane >> 1) & (PIECES - 1)) << 1;
+                while (any_lane(marks != 0)) {
+                    if (marks != 0) {
+                        const uint32_t j = (uint32_t)__clz((int)marks);
+                        const uint32_t run = j - pos;
+                        // nothing changed over the run: same value, same interval
+                        e.pts_lo += run * (uint32_t)e.stored_delta;
+                        const uint32_t tsj = *reinterpret_cast<const uint32_t*>(tile_ts + lane * TT::ROW + ((j ^ tswz) << 2));
+                        const uint64_t vj = *reinterpret_cast<const uint64_t*>(tile_val + lane * ROW_BYTES + ((j ^ vswz) << 3));
+                        const typename Encoder<FMT>::Code cd = e.code_next(tsj, 0u, vj);
+                        const uint32_t zl = 2u * run, len = cd.hlen + cd.plen;
+                        if (all_lanes(zl + len <= 64u)) {
+                            e.put((cd.head << cd.plen) | cd.pay, zl + len, sink);  // plen <= 62 here
+                        } else {
+                            e.put(0ull, zl, sink);
+                            e.emit(cd, sink);
+                        }
+                        pos = j + 1;
+                        marks &= ~(0x80000000u >> j);
+                    }
+                    steps++;
+                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
+                }
+                if (!idle) {
+                    e.put(0ull, 2u * (CH - pos), sink);  // the run that ends the chunk
+                    e.pts_lo = pt;
+                    e.stored_delta = (int64_t)(int32_t)pd;
+                    e.prev = pv;
+                }
+                if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
+                if (steps > 12) run_wait = 8;  // nearly every point differs from the one before: nothing to skip
+            } else if (plain_chunk) {
+                if (run_wait) run_wait--;
 #pragma unroll 1
                 for (uint32_t q = 0; q < PIECES; q += 2) {
                     const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
@@ -1369,6 +1431,8 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
             if (a.long_threshold == 0) return hipSuccess;  // forced: nothing is left for the lanes
         }
         EncodeArgs g = a;
+        static const bool no_run_skip = [] { const char* e = getenv("GTSC_RUN_SKIP"); return e && !strcmp(e, "0"); }();  // tests
+        g.run_skip = no_run_skip ? 0u : 1u;
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
         // Arrays on different phases of a 128-byte line take the SPLIT form: needed when the addresses differ

@@ -27,6 +27,7 @@ struct EncodeArgs {
     // set by the launcher: series with at least this many points are coded by the wave-per-block
     // kernel and left alone by the lane-per-series kernels (~0: no such series)
     uint64_t long_threshold;
+    uint32_t run_skip;     // set by the launcher: the tiled kernel may code chunks by run skipping (see encode_tiled_kernel)
 };
 
 struct DecodeArgs {

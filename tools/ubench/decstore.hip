@@ -89,6 +89,39 @@ __global__ __launch_bounds__(64) void rows_split_kernel(char* ts, char* val, siz
     }
 }
 
+// the decompressor's own geometry: rows of any length on a grid of 128-byte lines (a row's first and last
+// line may be shared with its neighbours: only the row's own bytes are written), the 64 rows of a wave
+// 2^shift apart; GAP: s_sleep units between steps
+template <bool NT, int GAP>
+__global__ __launch_bounds__(64) void rows_aligned_kernel(char* ts, char* val, size_t row_bytes, size_t nrows, unsigned shift)
+{
+    const unsigned lane = threadIdx.x, block = blockIdx.x;
+    const unsigned r = block & ((8u << shift) - 1u);
+    const size_t group = ((size_t)(block >> (3 + shift)) << 3) + (r & 7u);
+    const size_t row0 = (group << (6 + shift)) + (r >> 3);
+    const unsigned piece = lane % 8, lrow = lane / 8;
+    const size_t steps = (row_bytes + 127 + 64) / 128;
+    for (size_t c = 0; c < steps; c++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const size_t row = row0 + ((size_t)(lrow + i * 8) << shift);
+            const size_t lo = row * row_bytes, hi = lo + row_bytes;
+            const size_t o = (lo & ~(size_t)127) + c * 128 + piece * 16;
+            if (row < nrows && o >= lo && o + 16 <= hi) {
+                const U4 v = {(unsigned)row, (unsigned)c, lane, 1u};
+                if (NT) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<U4*>(ts + o));
+                    __builtin_nontemporal_store(v, reinterpret_cast<U4*>(val + o));
+                } else {
+                    *reinterpret_cast<U4*>(ts + o) = v;
+                    *reinterpret_cast<U4*>(val + o) = v;
+                }
+            }
+        }
+        if (GAP) __builtin_amdgcn_s_sleep(GAP);
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void seq_kernel(char* ts, char* val, size_t bytes)
 {
@@ -155,6 +188,15 @@ int main(int argc, char** argv)
     rep("rows, 256 B per step, streaming, gap 64", timeit([&] { rows_kernel<256, true, 64><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
     rep("rows, 256 B per step, streaming, gap 127", timeit([&] { rows_kernel<256, true, 127><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
     rep("rows, 128 B, streaming, phase pairs (shift 1)", timeit([&] { rows_kernel<128, true, 32><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 1); }));
+    {
+        const unsigned shift = (P % 16 == 0) ? 0 : 1;  // P = 120: rows of equal phase are two apart
+        const size_t per = 64ull << shift, groups = (nrows + per - 1) / per;
+        const unsigned gblocks = (unsigned)((shift ? ((groups + 7) & ~7ull) : groups) << shift);
+        rep("rows on the line grid, as the decompressor, 8 waves/CU", timeit([&] { rows_aligned_kernel<true, 0><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, gap 64", timeit([&] { rows_aligned_kernel<true, 64><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, plain stores", timeit([&] { rows_aligned_kernel<false, 0><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, consecutive rows per wave", timeit([&] { rows_aligned_kernel<true, 0><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+    }
     CK(hipGetLastError());
     return 0;
 }
