@@ -299,6 +299,10 @@ __device__ __forceinline__ void encode_block(const EncodeArgs& a, uint64_t s, ui
         stage[0] = 0;
         // a block beyond the point limit was coded up to the limit: reported, not silent
         const uint32_t st = (nwords > w.cap || np64 > BLOCK_MAX_POINTS) ? ST_OVERFLOW : 0u;
+        if (a.stats && (s & 63u) == 0) {  // how dense the streams are: a sample for the library's choice of kernel
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, (unsigned long long)nwords);
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 4, (unsigned long long)np64);
+        }
         a.out_nwords[s] = nwords;
         if (a.out_nbits) a.out_nbits[s] = nbits;
         if (a.status) a.status[s] = st;

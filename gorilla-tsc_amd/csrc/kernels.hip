@@ -597,6 +597,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
     }
+    // How dense the streams are (words written, points coded): one wave in 64 reports, the library chooses
+    // the kernel for long blocks of the batches that follow from the ratio.
+    if (a.stats && (blockIdx.x & 63u) == 0) {
+        uint32_t words = valid ? e.widx : 0u, points = np;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) {
+            words += (uint32_t)__shfl_xor((int)words, k, 64);
+            points += (uint32_t)__shfl_xor((int)points, k, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, (unsigned long long)words);
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 4, (unsigned long long)points);
+        }
+    }
 }
 
 // Decoder geometry.  Output tiles hold 16 slots per row like the encoder's: stores of whole
@@ -927,12 +941,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     // in ten changes).  The lane writes only the values that changed to its tile row, marks their slots, and
     // leaves (timestamp before the chunk, delta) for the flush, which fills in the rest: the latest marked
     // slot at or before each slot gives its value, the slot number times the delta its timestamp.
-    // A chunk qualifies when all 64 rows are under way, past their first point, with 16 slots to fill and a
-    // delta of 0..2^32-1.  Whatever is not ordinary in any lane (a timestamp code other than '0', end of
+    // A chunk qualifies when all rows of the wave are under way, past their first point, with 16 slots to fill
+    // and a delta of 0..2^32-1 (lanes without a series, in a batch's last wave, sit it out).  Whatever is not ordinary in any lane (a timestamp code other than '0', end of
     // stream, a window never defined, words not yet in the ring, a timestamp whose high half moves) drops
     // the attempt: the lanes go back to where the chunk began and take the lock-step loop, which knows all
     // of that; nothing the attempt did needs undoing (it lands no top-ups and the tile is rewritten).
     uint32_t run_wait = 0;     // wave-uniform: chunks to sit out before the next attempt
+    const uint64_t valid_m = lanes(valid);
+    if constexpr (RUN_SKIP) runs[lane] = U4{0u, 0u, 1u, 0u};  // a row without a series: never stored, but looked at
 #ifdef GTSC_RUNSTAT
     uint32_t rs_try = 0, rs_ok = 0, rs_steps = 0, rs_chunks = 0; uint64_t rs_why = 0;
 #endif
@@ -954,13 +970,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if constexpr (RUN_SKIP) {
             if (run_wait) {
                 run_wait--;
-            } else if (a.run_skip && c != 0 && dense == 0 && slow_m == 0 && active_m == ~0ull &&
-                       (lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) == 0) {
+            } else if (a.run_skip && c != 0 && dense == 0 && slow_m == 0 && active_m == valid_m &&
+                       ((lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) & valid_m) == 0) {
                 const WindowDecoder<FMT> d_at = d;
                 const uint64_t w0_at = w0, w1_at = w1, w2_at = w2;
                 const uint64_t delta = (uint64_t)d.stored_delta;
                 *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
-                uint32_t k = 0;       // slots of the chunk the lane has behind it
+                uint32_t k = valid ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series: all)
                 uint32_t steps = 0;
                 uint64_t bad_m = 0;
                 while (any_lane(k < DCH)) {
@@ -995,7 +1011,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                         *reinterpret_cast<uint64_t*>(my_vals + (((k + m) ^ swz) << 3)) = t.val;
                         run_slots |= 1u << (k + m);
                     }
-                    bad_m |= lanes(t.widx >= guard);
+                    bad_m |= lanes(t.widx >= guard) & valid_m;
                     d = t;
                     k += cnt;
                     n += cnt;
@@ -1003,7 +1019,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     GTSC_WINDOW_READ()
                     if (bad_m) break;
                 }
-                bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref);
+                bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref) & valid_m;
 #ifdef GTSC_RUNSTAT
                 rs_try++; rs_steps += steps; if (bad_m == 0) rs_ok++;
 #endif
@@ -1087,7 +1103,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #pragma unroll
         for (uint32_t i = 0; i < PASSES; i++) ri[i] = *reinterpret_cast<const U4*>(&rows[lrow + i * ROWS_PER_PASS]);
         if (RUN_SKIP && skipped) {
-            // a chunk decoded by run skipping (every row has all 16 slots): a slot's value is the one written at
+            // a chunk decoded by run skipping (every row that has a series has all 16 slots): a slot's value is the one written at
             // the latest marked slot at or before it, its timestamp the one before the chunk plus (slot + 1) deltas
             uint64_t q0[PASSES], q1[PASSES];
             uint32_t t0[PASSES], t1[PASSES];
@@ -1108,6 +1124,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
                 const U4 t = {t0[i], ri[i].w, t1[i], ri[i].w};
                 const U4 v = {(uint32_t)q0[i], (uint32_t)(q0[i] >> 32), (uint32_t)q1[i], (uint32_t)(q1[i] >> 32)};
+                if (ri[i].z != DEC_ROW_FULL) continue;  // a row without a series
 #if GTSC_ABLATE == 4
                 asm volatile("" ::"v"(t), "v"(v), "v"(idx));
 #else
@@ -1404,6 +1421,17 @@ static uint64_t long_points()
     return v;
 }
 
+// From how many long blocks of sparse streams on a batch goes to the lane-per-series compressor
+// (GTSC_SPARSE_TILED_MIN overrides it; tests).
+static uint64_t sparse_tiled_min()
+{
+    static const uint64_t v = [] {
+        const char* e = getenv("GTSC_SPARSE_TILED_MIN");
+        return e ? strtoull(e, nullptr, 10) : 57344ull;
+    }();
+    return v;
+}
+
 hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
 {
     if (a0.nseries == 0) return hipSuccess;
@@ -1417,8 +1445,10 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
-    } else if (!a.pts.off && a.pts.uniform >= long_points()) {
-        // a uniform batch of long blocks: all of it is the wave-per-block kernel's
+    } else if (!a.pts.off && a.pts.uniform >= long_points() && !(a.sparse && format == FMT_V2 && a.nseries >= sparse_tiled_min())) {
+        // a uniform batch of long blocks: all of it is the wave-per-block kernel's -- unless the streams are
+        // sparse and the blocks many: a lane per series then skips their runs of unchanged points and is
+        // the faster one once the lanes fill the machine (65,536 x 7,200 gauges: 1.53 against 1.90 ms)
         a.long_threshold = 0;
         return launch_encode_blocks(a, format, stream);
     } else {

@@ -28,6 +28,10 @@ struct EncodeArgs {
     // kernel and left alone by the lane-per-series kernels (~0: no such series)
     uint64_t long_threshold;
     uint32_t run_skip;     // set by the launcher: the tiled kernel may code chunks by run skipping (see encode_tiled_kernel)
+    // from the caller: what the streams compressed before looked like -- 1 = a few bits per point (long blocks of such
+    // streams are then left to the lane-per-series kernel when the batch is large), 0 = dense or unknown
+    uint32_t sparse;
+    uint64_t* stats;       // may be null: [3] += words written, [4] += points coded (a sample of the blocks)
 };
 
 struct DecodeArgs {
