@@ -126,6 +126,7 @@ EXTRA_WORKLOADS = [
     ("random_walk_262144x7200", "random_walk", 262_144, 7200),
     ("adversarial_65536x7200", "adversarial", 65_536, 7200),
     ("gauge_16668x7200", "gauge", 16_668, 7200),
+    ("gauge_262144x7200", "gauge", 262_144, 7200),
 ]
 
 
