@@ -41,6 +41,16 @@ def make_workload(name, S, P, device, seed):
         step[:, 0] = 0
         v = start + torch.cumsum(step, dim=1)
         del r, step
+    elif name.startswith("gauge_p"):
+        # the same gauge with another share of changing values: gauge_p30 = 30 % of the steps move it
+        cadence = 60000
+        pr = int(name[7:]) / 100.0
+        start = torch.randint(0, 1001, (S, 1), device=device, generator=g).double()
+        r = torch.rand((S, P), device=device, generator=g)
+        step = torch.where(r < pr / 2, -1.0, torch.where(r < pr, 1.0, 0.0)).double()
+        step[:, 0] = 0
+        v = start + torch.cumsum(step, dim=1)
+        del r, step
     elif name == "gauge_drift":
         # slow drift rounded to 2 decimals (about 33 bits/point)
         cadence = 60000

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
 #define GTSC_TICK(acc_)
 #endif
     uint32_t run_wait = 0;  // wave-uniform: chunks to code in lock step before run skipping is tried again
+    uint32_t run_backoff = 4;
     wave_sync();  // rows[] visible
     if (nchunks) GTSC_FETCH(0)
     GTSC_TICK(tk_fetch)
@@ -509,7 +510,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     e.prev = pv;
                 }
                 if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
-                if (steps > 12) run_wait = 8;  // nearly every point differs from the one before: nothing to skip
+                // from eight steps on the lock-step loop is the quicker one: streams whose points differ from the
+                // one before that often sit out more and more chunks
+                if (steps > 7) {
+                    run_wait = run_backoff;
+                    run_backoff = run_backoff < 32 ? run_backoff * 2 : 64;
+                } else {
+                    run_backoff = 4;
+                }
             } else if (plain_chunk) {
                 if (run_wait) run_wait--;
 #pragma unroll 1
@@ -1025,8 +1033,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #endif
                 if (bad_m == 0) {
                     skipped = true;
-                    run_backoff = 1;
-                    if (steps > 12) run_wait = 8;  // nearly every value changes: nothing to skip
+                    // a chunk of ten steps or more would have been quicker in lock step (nine is where the two meet):
+                    // streams whose values change that often sit out more and more chunks, like failed attempts
+                    if (steps > 9) {
+                        run_wait = run_backoff < 4 ? 4 : run_backoff;
+                        run_backoff = run_wait < 32 ? run_wait * 2 : 64;
+                    } else {
+                        run_backoff = 1;
+                    }
                     if (pend) GTSC_TOPUP_LAND()
                     const bool low = d.widx >= limit;
                     if (low) GTSC_TOPUP_ISSUE()
