@@ -949,13 +949,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     // in ten changes).  The lane writes only the values that changed to its tile row, marks their slots, and
     // leaves (timestamp before the chunk, delta) for the flush, which fills in the rest: the latest marked
     // slot at or before each slot gives its value, the slot number times the delta its timestamp.
-    // A chunk qualifies when all rows of the wave are under way, past their first point, with 16 slots to fill
-    // and a delta of 0..2^32-1 (lanes without a series, in a batch's last wave, sit it out).  Whatever is not ordinary in any lane (a timestamp code other than '0', end of
+    // A chunk qualifies when every row of the wave that is still under way is past its first point, has 16 slots
+    // to fill and a delta of 0..2^32-1 (lanes without a series, or past the end of theirs, sit it out).  Whatever is not ordinary in any lane (a timestamp code other than '0', end of
     // stream, a window never defined, words not yet in the ring, a timestamp whose high half moves) drops
     // the attempt: the lanes go back to where the chunk began and take the lock-step loop, which knows all
     // of that; nothing the attempt did needs undoing (it lands no top-ups and the tile is rewritten).
     uint32_t run_wait = 0;     // wave-uniform: chunks to sit out before the next attempt
-    const uint64_t valid_m = lanes(valid);
     if constexpr (RUN_SKIP) runs[lane] = U4{0u, 0u, 1u, 0u};  // a row without a series: never stored, but looked at
 #ifdef GTSC_RUNSTAT
     uint32_t rs_try = 0, rs_ok = 0, rs_steps = 0, rs_chunks = 0; uint64_t rs_why = 0;
@@ -978,13 +977,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if constexpr (RUN_SKIP) {
             if (run_wait) {
                 run_wait--;
-            } else if (a.run_skip && c != 0 && dense == 0 && slow_m == 0 && active_m == valid_m &&
-                       ((lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) & valid_m) == 0) {
+            } else if (a.run_skip && c != 0 && dense == 0 && slow_m == 0 &&
+                       ((lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) & active_m) == 0) {
                 const WindowDecoder<FMT> d_at = d;
                 const uint64_t w0_at = w0, w1_at = w1, w2_at = w2;
                 const uint64_t delta = (uint64_t)d.stored_delta;
                 *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
-                uint32_t k = valid ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series: all)
+                uint32_t k = active ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series, or past its end: all)
                 uint32_t steps = 0;
                 uint64_t bad_m = 0;
                 while (any_lane(k < DCH)) {
@@ -1019,7 +1018,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                         *reinterpret_cast<uint64_t*>(my_vals + (((k + m) ^ swz) << 3)) = t.val;
                         run_slots |= 1u << (k + m);
                     }
-                    bad_m |= lanes(t.widx >= guard) & valid_m;
+                    bad_m |= lanes(t.widx >= guard) & active_m;
                     d = t;
                     k += cnt;
                     n += cnt;
@@ -1027,7 +1026,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     GTSC_WINDOW_READ()
                     if (bad_m) break;
                 }
-                bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref) & valid_m;
+                bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref) & active_m;
 #ifdef GTSC_RUNSTAT
                 rs_try++; rs_steps += steps; if (bad_m == 0) rs_ok++;
 #endif
@@ -1138,7 +1137,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
                 const U4 t = {t0[i], ri[i].w, t1[i], ri[i].w};
                 const U4 v = {(uint32_t)q0[i], (uint32_t)(q0[i] >> 32), (uint32_t)q1[i], (uint32_t)(q1[i] >> 32)};
-                if (ri[i].z != DEC_ROW_FULL) continue;  // a row without a series
+                if (ri[i].z != DEC_ROW_FULL) continue;  // a row without a series, or one that has ended
 #if GTSC_ABLATE == 4
                 asm volatile("" ::"v"(t), "v"(v), "v"(idx));
 #else
