@@ -551,8 +551,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 }
             }
         } else if (all_lanes(interior || idle)) {
-            // v1, every lane has all 16 slots occupied: no guards, and pairs of ordinary points
-            // (past the first one, no zero timestamp before the second) go through together
+            // v1, every lane has all 16 slots occupied.  Run skipping as above, with 64-bit timestamps; a zero
+            // timestamp anywhere in the chunk (the "no point yet" test) leaves the chunk to the loop below.
+            bool skipped = false;
+            if (a.run_skip && run_wait == 0 && all_lanes(idle || e.started)) {
+                uint32_t marks = 0, zeros = 0;
+                uint64_t pt = ((uint64_t)e.pts_hi << 32) | e.pts_lo, pd = (uint64_t)e.stored_delta, pv = e.prev;
+#pragma unroll
+                for (uint32_t q = 0; q < PIECES; q++) {
+                    const U4 t = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q));
+                    const U4 v = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
+                    const uint64_t tj[2] = {lo64(t), hi64(t)}, vj[2] = {lo64(v), hi64(v)};
+#pragma unroll
+                    for (uint32_t i = 0; i < 2; i++) {
+                        const uint64_t nd = tj[i] - pt;
+                        const bool other = (nd != pd) | (vj[i] != pv);
+                        marks |= other ? 0x80000000u >> (2 * q + i) : 0u;
+                        zeros |= tj[i] == 0 ? 1u : 0u;
+                        pt = tj[i]; pd = nd; pv = vj[i];
+                    }
+                }
+                if (!any_lane(zeros != 0 && !idle)) {
+                    skipped = true;
+                    if (idle) marks = 0;
+                    uint32_t pos = 0, steps = 0;
+                    const uint32_t vswz = ((lane >> 1) & (PIECES - 1)) << 1;
+                    while (any_lane(marks != 0)) {
+                        if (marks != 0) {
+                            const uint32_t j = (uint32_t)__clz((int)marks);
+                            const uint32_t run = j - pos;
+                            const uint64_t before = (((uint64_t)e.pts_hi << 32) | e.pts_lo) + (uint64_t)run * (uint64_t)e.stored_delta;
+                            e.pts_lo = (uint32_t)before; e.pts_hi = (uint32_t)(before >> 32);
+                            const uint64_t tsj = *reinterpret_cast<const uint64_t*>(tile_ts + lane * TT::ROW + ((j ^ vswz) << 3));
+                            const uint64_t vj = *reinterpret_cast<const uint64_t*>(tile_val + lane * ROW_BYTES + ((j ^ vswz) << 3));
+                            const typename Encoder<FMT>::Code cd = e.code_next((uint32_t)tsj, (uint32_t)(tsj >> 32), vj);
+                            const uint32_t zl = 2u * run, len = cd.hlen + cd.plen;
+                            if (all_lanes(zl + len <= 64u)) {
+                                e.put((cd.head << cd.plen) | cd.pay, zl + len, sink);
+                            } else {
+                                e.put(0ull, zl, sink);
+                                e.emit(cd, sink);
+                            }
+                            pos = j + 1;
+                            marks &= ~(0x80000000u >> j);
+                        }
+                        steps++;
+                        if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
+                    }
+                    if (!idle) {
+                        e.put(0ull, 2u * (CH - pos), sink);
+                        e.pts_lo = (uint32_t)pt; e.pts_hi = (uint32_t)(pt >> 32);
+                        e.stored_delta = (int64_t)pd;
+                        e.prev = pv;
+                    }
+                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
+                    if (steps > 7) {
+                        run_wait = run_backoff;
+                        run_backoff = run_backoff < 32 ? run_backoff * 2 : 64;
+                    } else {
+                        run_backoff = 4;
+                    }
+                }
+            } else if (run_wait) {
+                run_wait--;
+            }
+            // otherwise: no guards, and pairs of ordinary points (past the first one, no zero timestamp
+            // before the second) go through together
+            if (!skipped) {
 #pragma unroll 1
             for (uint32_t q = 0; q < PIECES; q++) {
                 const U4 t = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q));
@@ -568,6 +633,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                 }
                 if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
             }
+            }  // !skipped
         } else {
 #pragma unroll 1
             for (uint32_t q = 0; q < PIECES; q++) {
@@ -1458,7 +1524,7 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
-    } else if (!a.pts.off && a.pts.uniform >= long_points() && !(a.sparse && format == FMT_V2 && a.nseries >= sparse_tiled_min())) {
+    } else if (!a.pts.off && a.pts.uniform >= long_points() && !(a.sparse && a.nseries >= sparse_tiled_min())) {
         // a uniform batch of long blocks: all of it is the wave-per-block kernel's -- unless the streams are
         // sparse and the blocks many: a lane per series then skips their runs of unchanged points and is
         // the faster one once the lanes fill the machine (65,536 x 7,200 gauges: 1.53 against 1.90 ms)
