@@ -11,6 +11,7 @@ bash tools/profile.sh ${TAG}_default > $OUT/prof_default.log 2>&1 || { echo "pro
 bash tools/profile.sh ${TAG}_drift --workload gauge_drift > $OUT/prof_drift.log 2>&1 || { echo "profile drift failed"; exit 1; }
 bash tools/profile.sh ${TAG}_rw --workload random_walk --series 262144 --points 7200 > $OUT/prof_rw.log 2>&1 || { echo "profile rw failed"; exit 1; }
 bash tools/profile.sh ${TAG}_adv --workload adversarial --series 65536 --points 7200 > $OUT/prof_adv.log 2>&1 || { echo "profile adv failed"; exit 1; }
+bash tools/profile.sh ${TAG}_gauge7200 --workload gauge --series 262144 --points 7200 > $OUT/prof_gauge7200.log 2>&1 || { echo "profile gauge7200 failed"; exit 1; }
 for W in gauge random_walk; do
   timeout -k 10 300 python bench.py --workload $W --series 524288 --points 7200 --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $OUT/cfg3_share_524288x7200_$W.json 2>/dev/null || { echo "cfg3 share $W failed"; exit 1; }
 done
