@@ -258,13 +258,15 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the round-trip check (kernel experiments only)")
     ap.add_argument("--val-phase", type=int, default=0, help="start the value array this many 8-byte words into its allocation "
                     "(diagnostic: an odd number puts it on the other 16-byte phase than the timestamps)")
+    ap.add_argument("--out-phase", type=int, default=0, help="start the decoded value array this many 8-byte words into its allocation "
+                    "(diagnostic: where the two output streams fall relative to each other)")
     ap.add_argument("--format", default="v2", choices=["v2", "v1"], help="v2 = GorillaCompressor (the default), v1 = Compressor")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    default_variant = args.format == "v2" and not args.val_phase and not args.slot_words
+    default_variant = args.format == "v2" and not args.val_phase and not args.slot_words and not args.out_phase
     extras = (world == 1 and not args.no_extras and default_variant
               and (args.workload, args.series, args.points) == ("gauge", 1_000_000, 120))
     # The host-to-host figures come from child processes that run before this process touches the GPU: two
@@ -311,7 +313,11 @@ def main():
         out = torch.zeros(S * slot, dtype=torch.int64, device=device)
         nw = torch.zeros(S, dtype=torch.int64, device=device)
         ts2 = torch.zeros_like(ts)
-        val2 = torch.zeros_like(val)
+        if args.out_phase:
+            big2 = torch.zeros(val.numel() + args.out_phase, dtype=val.dtype, device=device)
+            val2 = big2[args.out_phase:]
+        else:
+            val2 = torch.zeros_like(val)
         npts = torch.zeros(S, dtype=torch.int64, device=device)
 
         def encode():

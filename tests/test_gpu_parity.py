@@ -661,6 +661,38 @@ def test_lock_step_decoder_in_its_own_process():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_sparse_long_blocks_after_a_sync(ctx):
+    """Once a context has seen sparse streams (gtsc_sync reads the density counters), uniform batches of long
+    blocks go to the lane-per-series compressor when they hold many blocks.  GTSC_SPARSE_TILED_MIN=0 makes "many"
+    any number (read once per process: the test runs itself in a child): the same batch compressed before and
+    after the sync -- by the wave-per-block kernel, then by the lane-per-series kernel -- gives the oracle's words
+    both times, in both formats, and decodes to its input."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GTSC_SPARSE_TILED_MIN") != "0":
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                            "-k", "sparse_long_blocks_after_a_sync"], env=dict(os.environ, GTSC_SPARSE_TILED_MIN="0"),
+                           capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    for gfmt, ofmt in FMTS:
+        fresh = G.Context(0)
+        try:
+            b = synth.gauge_integer(S=700, P=3000, seed=21)
+            for _ in range(3):  # the first call knows nothing about the streams; the later ones do
+                out, off, nw, d_out, d_nw = check_encode_against_oracle(fresh, b, gfmt, ofmt, uniform=True)
+                ts, val, npts, st, rc = gpu_decode(fresh, out, off, nw, b.pt_off, gfmt, uniform_cap=3000, d_words=d_out)
+                assert rc == 0 and not st.any()
+                assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+            dense = synth.random_walk(S=300, P=2000)  # a dense batch right after: the choice made for sparse streams
+            check_encode_against_oracle(fresh, dense, gfmt, ofmt, uniform=True)
+            check_encode_against_oracle(fresh, dense, gfmt, ofmt, uniform=True)
+        finally:
+            fresh.close()
+
+
 def test_lane_per_series_kernels_in_their_own_process():
     """The plain lane-per-series kernels (both formats) are what GTSC_KERNEL=direct selects; the choice is read
     once per process, so the sweep runs in a child process for a few seconds."""
