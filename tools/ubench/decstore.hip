@@ -122,6 +122,44 @@ __global__ __launch_bounds__(64) void rows_aligned_kernel(char* ts, char* val, s
     }
 }
 
+// the same geometry with the store's cache-policy bits spelled out (MODE: 0 none, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 nt,
+// 6 sc1 nt, 7 sc0 sc1 nt)
+template <int MODE>
+__device__ __forceinline__ void store_mode(char* p, U4 v)
+{
+    if (MODE == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (MODE == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void rows_mode_kernel(char* ts, char* val, size_t row_bytes, size_t nrows, unsigned shift)
+{
+    const unsigned lane = threadIdx.x, block = blockIdx.x;
+    const unsigned r = block & ((8u << shift) - 1u);
+    const size_t group = ((size_t)(block >> (3 + shift)) << 3) + (r & 7u);
+    const size_t row0 = (group << (6 + shift)) + (r >> 3);
+    const unsigned piece = lane % 8, lrow = lane / 8;
+    const size_t steps = (row_bytes + 127 + 64) / 128;
+    for (size_t c = 0; c < steps; c++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const size_t row = row0 + ((size_t)(lrow + i * 8) << shift);
+            const size_t lo = row * row_bytes, hi = lo + row_bytes;
+            const size_t o = (lo & ~(size_t)127) + c * 128 + piece * 16;
+            if (row < nrows && o >= lo && o + 16 <= hi) {
+                const U4 v = {(unsigned)row, (unsigned)c, lane, 1u};
+                store_mode<MODE>(ts + o, v);
+                store_mode<MODE>(val + o, v);
+            }
+        }
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void seq_kernel(char* ts, char* val, size_t bytes)
 {
@@ -196,6 +234,14 @@ int main(int argc, char** argv)
         rep("the same, gap 64", timeit([&] { rows_aligned_kernel<true, 64><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
         rep("the same, plain stores", timeit([&] { rows_aligned_kernel<false, 0><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
         rep("the same, consecutive rows per wave", timeit([&] { rows_aligned_kernel<true, 0><<<blocks, 64, 19968>>>(ts, val, row_bytes, nrows, 0); }));
+        rep("the same, store policy: none", timeit([&] { rows_mode_kernel<0><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: nt", timeit([&] { rows_mode_kernel<1><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: sc0", timeit([&] { rows_mode_kernel<2><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: sc1", timeit([&] { rows_mode_kernel<3><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: sc0 sc1", timeit([&] { rows_mode_kernel<4><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: sc0 nt", timeit([&] { rows_mode_kernel<5><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: sc1 nt", timeit([&] { rows_mode_kernel<6><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
+        rep("the same, store policy: sc0 sc1 nt", timeit([&] { rows_mode_kernel<7><<<gblocks, 64, 19968>>>(ts, val, row_bytes, nrows, shift); }));
     }
     CK(hipGetLastError());
     return 0;
