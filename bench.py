@@ -51,6 +51,15 @@ def make_workload(name, S, P, device, seed):
         step[:, 0] = 0
         v = start + torch.cumsum(step, dim=1)
         del r, step
+    elif name.startswith("gauge_jit"):
+        # the gauge with one timestamp in N a millisecond late: gauge_jit1000
+        cadence = 60000
+        start = torch.randint(0, 1001, (S, 1), device=device, generator=g).double()
+        r = torch.rand((S, P), device=device, generator=g)
+        step = torch.where(r < 0.05, -1.0, torch.where(r < 0.10, 1.0, 0.0)).double()
+        step[:, 0] = 0
+        v = start + torch.cumsum(step, dim=1)
+        del r, step
     elif name == "gauge_drift":
         # slow drift rounded to 2 decimals (about 33 bits/point)
         cadence = 60000
@@ -70,6 +79,9 @@ def make_workload(name, S, P, device, seed):
     if name == "adversarial":
         jit = torch.randint(-400, 400, (S, P), device=device, generator=g, dtype=torch.int64)
         ts = (ts_row[None, :] + jit).reshape(-1).contiguous()
+    elif name.startswith("gauge_jit"):
+        late = (torch.rand((S, P), device=device, generator=g) < 1.0 / int(name[9:])).to(torch.int64)
+        ts = (ts_row[None, :] + late).reshape(-1).contiguous()
     else:
         ts = ts_row.repeat(S, 1).reshape(-1).contiguous()
     block = torch.full((S,), synth.BLOCK_TS, dtype=torch.int64, device=device)

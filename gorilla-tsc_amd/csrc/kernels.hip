@@ -1016,8 +1016,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     // leaves (timestamp before the chunk, delta) for the flush, which fills in the rest: the latest marked
     // slot at or before each slot gives its value, the slot number times the delta its timestamp.
     // A chunk qualifies when every row of the wave that is still under way is past its first point, has 16 slots
-    // to fill and a delta of 0..2^32-1 (lanes without a series, or past the end of theirs, sit it out).  Whatever is not ordinary in any lane (a timestamp code other than '0', end of
-    // stream, a window never defined, words not yet in the ring, a timestamp whose high half moves) drops
+    // to fill and a delta of 0..2^32-1 (lanes without a series, or past the end of theirs, sit it out).  A point that changes the
+    // interval (a timestamp code other than '0') is parsed like a changed value; its timestamp and the next
+    // one's go to the timestamp tile for the flush.  Whatever is not ordinary in any lane (end of stream, a
+    // delta outside 0..2^32-1, a window never defined, words not yet in the ring, a timestamp whose high half moves) drops
     // the attempt: the lanes go back to where the chunk began and take the lock-step loop, which knows all
     // of that; nothing the attempt did needs undoing (it lands no top-ups and the tile is rewritten).
     uint32_t run_wait = 0;     // wave-uniform: chunks to sit out before the next attempt
@@ -1039,6 +1041,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (c != 0 && run_wait == 0) rs_why |= (dense != 0 ? 1u : 0u) | (slow_m != 0 ? 2u : 0u) | (active_m != ~0ull ? 4u : 0u) | (lanes(n + DCH > cap) ? 8u : 0u) | (lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u) ? 16u : 0u);
 #endif
         uint32_t run_slots = 1u;   // slots of the chunk whose values the lane wrote (slot 0: the value before the chunk)
+        uint32_t run_stamps = 0;   // slots of the chunk whose timestamps the lane wrote (see below)
         const uint32_t run_ts = (uint32_t)d.stored_ts, run_delta = (uint32_t)d.stored_delta;
         if constexpr (RUN_SKIP) {
             if (run_wait) {
@@ -1047,7 +1050,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                        ((lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) & active_m) == 0) {
                 const WindowDecoder<FMT> d_at = d;
                 const uint64_t w0_at = w0, w1_at = w1, w2_at = w2;
-                const uint64_t delta = (uint64_t)d.stored_delta;
                 *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
                 uint32_t k = active ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series, or past its end: all)
                 uint32_t steps = 0;
@@ -1069,13 +1071,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     const uint64_t u2 = w2;
                     const uint32_t off2 = t.off;
                     auto lo2 = [u1, u2, off2] { return WindowDecoder<FMT>::window(u1, u2, off2); };
-                    const typename WindowDecoder<FMT>::Parsed p = t.template parse<true>(hi2, lo2);
                     const uint64_t more_m = lanes(m < room);  // lanes with a point to parse
-                    bad_m |= more_m & (lanes((int64_t)hi2 < 0) | (lanes(p.changed) & lanes(p.nbits == 0)) |
+                    // the timestamp code: '0' in every lane as a rule; an irregular interval somewhere takes the
+                    // general parse for the step (end of stream is the lock-step loop's)
+                    typename WindowDecoder<FMT>::Parsed p;
+                    uint64_t eos_m = 0;
+                    if ((lanes((int64_t)hi2 < 0) & more_m) == 0) {
+                        p = t.template parse<true>(hi2, lo2);
+                    } else {
+                        p = t.template parse<false>(hi2, lo2);
+                        eos_m = lanes(p.eos);
+                    }
+                    bad_m |= more_m & (eos_m | (lanes(p.changed) & lanes(p.nbits == 0)) |
                                        (lanes(o >= 64u) & lanes(p.o3 - off2 > 64u)));
                     const bool more = m < room;
                     const uint32_t cnt = m + (more ? 1u : 0u);
-                    t.stored_ts = d.stored_ts + (uint64_t)cnt * delta;
+                    // the run keeps the delta; the point after it may change it (it has to stay within 0..2^32-1,
+                    // so that the chunk's timestamps never decrease: see the test of the high half below)
+                    const uint64_t delta = (uint64_t)d.stored_delta;
+                    const uint64_t delta2 = delta + (more ? (uint64_t)p.dd : 0ull);
+                    bad_m |= lanes((uint32_t)(delta2 >> 32) != 0u) & active_m;
+                    t.stored_delta = (int64_t)delta2;
+                    t.stored_ts = d.stored_ts + (uint64_t)m * delta + (more ? delta2 : 0ull);
                     if (more) {
                         t.nbits = p.nbits;
                         t.trail = p.trail;
@@ -1083,6 +1100,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                         t.advance(p.o3);
                         *reinterpret_cast<uint64_t*>(my_vals + (((k + m) ^ swz) << 3)) = t.val;
                         run_slots |= 1u << (k + m);
+                        if (delta2 != delta) {
+                            // the interval changed: this point's timestamp, and the next one's as the new delta
+                            // predicts it, go to the timestamp tile (a next point that changes the interval again
+                            // writes its own over it); the flush takes the delta from the two
+                            const uint32_t e = k + m;
+                            *reinterpret_cast<uint32_t*>(tile_ts + dec_ts_addr(lane, e)) = (uint32_t)t.stored_ts;
+                            if (e + 1 < DCH) *reinterpret_cast<uint32_t*>(tile_ts + dec_ts_addr(lane, e + 1)) = (uint32_t)t.stored_ts + (uint32_t)delta2;
+                            run_stamps |= (3u << e) & 0xFFFFu;
+                        }
                     }
                     bad_m |= lanes(t.widx >= guard) & active_m;
                     d = t;
@@ -1173,7 +1199,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         const uint32_t info = lo_rel | (hi_rel << 8) | (dmask << 16);
         *reinterpret_cast<uint2*>(&rows[lane].info) = make_uint2(info, ts_ref);
         if constexpr (RUN_SKIP) {
-            if (skipped) runs[lane] = U4{run_ts, run_delta, run_slots, 0u};
+            if (skipped) runs[lane] = U4{run_ts, run_delta, run_slots, run_stamps};
         }
         wave_sync();
         const uint32_t j0 = 2 * piece;
@@ -1184,9 +1210,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (RUN_SKIP && skipped) {
             // a chunk decoded by run skipping (every row that has a series has all 16 slots): a slot's value is the one written at
             // the latest marked slot at or before it, its timestamp the one before the chunk plus (slot + 1) deltas
+            // Rows whose interval changed inside the chunk hold timestamps in the tile at the slots marked in the
+            // record's fourth word, always in pairs (the point that changed it and the one after): a slot at a
+            // mark has that timestamp, a slot after the last mark the one there plus so many times the
+            // difference of the pair; before the first mark the row's own start and delta apply.
             uint64_t q0[PASSES], q1[PASSES];
             uint32_t t0[PASSES], t1[PASSES];
             const uint32_t upto0 = (2u << j0) - 1u, upto1 = (4u << j0) - 1u;  // slots 0..j0, 0..j0+1
+            const bool stamped = any_lane(run_stamps != 0);
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {
                 const uint32_t r = lrow + i * ROWS_PER_PASS;
@@ -1197,6 +1228,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 q1[i] = *reinterpret_cast<const uint64_t*>(tile_val + r * ROW_BYTES + ((s1 ^ rswz) << 3));
                 t0[i] = rr.x + (j0 + 1u) * rr.y;
                 t1[i] = t0[i] + rr.y;
+                if (stamped) {
+                    const uint32_t m0 = rr.w & upto0, m1 = rr.w & upto1;
+                    const uint32_t e0 = m0 ? 31u - (uint32_t)__clz((int)m0) : 1u, e1 = m1 ? 31u - (uint32_t)__clz((int)m1) : 1u;
+                    const uint32_t a0 = *reinterpret_cast<const uint32_t*>(tile_ts + dec_ts_addr(r, e0));
+                    const uint32_t b0 = *reinterpret_cast<const uint32_t*>(tile_ts + dec_ts_addr(r, e0 ? e0 - 1u : 0u));
+                    const uint32_t a1 = *reinterpret_cast<const uint32_t*>(tile_ts + dec_ts_addr(r, e1));
+                    const uint32_t b1 = *reinterpret_cast<const uint32_t*>(tile_ts + dec_ts_addr(r, e1 ? e1 - 1u : 0u));
+                    if (m0) t0[i] = a0 + (j0 - e0) * (a0 - b0);
+                    if (m1) t1[i] = a1 + (j0 + 1u - e1) * (a1 - b1);
+                }
             }
 #pragma unroll
             for (uint32_t i = 0; i < PASSES; i++) {

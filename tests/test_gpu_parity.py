@@ -602,6 +602,13 @@ def _run_skip_batch(S=256, P=200, seed=11):
         val[w + 21, ::7] ^= np.uint64(0x8000000000000001)     # payloads of 64 bits every seventh point
         ts[w + 23, 120] = ts[w + 23, 119]                     # a repeated timestamp (delta 0 from there)
         ts[w + 23, 121:] = ts[w + 23, 119]
+        for r_, every in ((25, 40), (27, 16), (29, 5), (31, 2)):  # late samples: the interval changes and comes back
+            late = rng.random(P) < 1.0 / every
+            ts[w + r_] += np.where(late, rng.integers(1, 3000, size=P), 0)
+        ts[w + 33] += np.cumsum(rng.integers(-30000, 30000, size=P))  # a new interval at every point, some of them negative
+        ts[w + 35, 15::16] += 7                                # the last slot of a chunk, every chunk
+        ts[w + 37, 16::16] += 7                                # the first slot
+        ts[w + 39, 14::16] += 7; ts[w + 39, 15::16] += 9       # the last two
     return synth.Batch(block, np.ascontiguousarray(ts.reshape(-1)), np.ascontiguousarray(val.reshape(-1)), g.pt_off)
 
 
