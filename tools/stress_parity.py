@@ -35,7 +35,14 @@ def make_batch(rng):
         return synth.ragged_mix(seed=int(rng.integers(1, 1 << 30)), nseries=int(rng.integers(6, 700)), pmax=int(rng.integers(2, 400)))
     if kind == 1:
         S, P = int(rng.integers(1, 600)), int(rng.integers(1, 260))
-        return synth.gauge_integer(S=S, P=P, seed=int(rng.integers(1, 1 << 30)))
+        b = synth.gauge_integer(S=S, P=P, seed=int(rng.integers(1, 1 << 30)))
+        if rng.integers(0, 2):
+            # late samples in some rows: intervals that change and come back inside runs of unchanged values
+            every = int(rng.choice([2, 5, 20, 100, 1000]))
+            late = (rng.random(b.ts.size) < 1.0 / every) & np.repeat(rng.random(S) < 0.5, P)
+            ts = b.ts + np.where(late, rng.integers(1, 3000, size=b.ts.size), 0)
+            b = synth.Batch(b.block_ts, ts, b.val, b.pt_off)
+        return b
     if kind == 2:
         S, P = int(rng.integers(1, 300)), int(rng.integers(1, 200))
         return synth.adversarial(S=S, P=P, seed=int(rng.integers(1, 1 << 30)))
