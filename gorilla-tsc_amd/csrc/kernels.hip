@@ -1007,6 +1007,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             GTSC_WINDOW_READ()                                                                 \
         }                                                                                      \
     }
+// One step of the run-skipping loop (see below); STAMPS: the form that takes interval changes along.
+#define GTSC_RUN_STEP(STAMPS)                                                                  \
+    {                                                                                                                                                          \
+                        /* the run: each '00' is a point; a lane that is through the chunk has no room and stays put */                                        \
+                        const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);                                                                         \
+                        const uint32_t zeros = (uint32_t)__clz((int)(uint32_t)(hi >> 32));  /* 32 when there is no one */                                      \
+                        const uint32_t room = DCH - k;                                                                                                         \
+                        const uint32_t m = (zeros >> 1) < room ? (zeros >> 1) : room;                                                                          \
+                        const uint32_t o = d.off + 2u * m;  /* <= 63 + 32 */                                                                                   \
+                        /* the point after the run, parsed from the words at hand: (w0,w1,w2), or (w1,w2) when */                                              \
+                        /* the run crossed into w1 -- a payload that needs the word after w2 then drops the attempt */                                         \
+                        WindowDecoder<FMT> t = d;                                                                                                              \
+                        t.widx = d.widx + (o >> 6);                                                                                                            \
+                        t.off = o & 63u;                                                                                                                       \
+                        const uint64_t u0 = o >= 64u ? w1 : w0, u1 = o >= 64u ? w2 : w1;                                                                       \
+                        const uint64_t hi2 = WindowDecoder<FMT>::window(u0, u1, t.off);                                                                        \
+                        const uint64_t u2 = w2;                                                                                                                \
+                        const uint32_t off2 = t.off;                                                                                                           \
+                        auto lo2 = [u1, u2, off2] { return WindowDecoder<FMT>::window(u1, u2, off2); };                                                        \
+                        const uint64_t more_m = lanes(m < room);  /* lanes with a point to parse */                                                            \
+                        typename WindowDecoder<FMT>::Parsed p;                                                                                                 \
+                        const bool more = m < room;                                                                                                            \
+                        const uint32_t cnt = m + (more ? 1u : 0u);                                                                                             \
+                        const uint64_t delta = (uint64_t)d.stored_delta;                                                                                       \
+                        const uint64_t neg_m = lanes((int64_t)hi2 < 0) & more_m;  /* timestamp codes other than '0' */                                         \
+                        if (!(STAMPS)) {                                                                                                                       \
+                            p = t.template parse<true>(hi2, lo2);                                                                                              \
+                            t.stored_ts = d.stored_ts + (uint64_t)cnt * delta;                                                                                 \
+                            irregular_m |= neg_m;                                                                                                              \
+                            bad_m |= neg_m;                                                                                                                    \
+                        } else {                                                                                                                               \
+                            p = t.template parse<false>(hi2, lo2);                                                                                             \
+                            bad_m |= lanes(p.eos) & more_m;  /* end of stream is the lock-step loop's */                                                       \
+                            /* the run keeps the delta; the point after it changes it (it has to stay within 0..2^32-1, */                                     \
+                            /* so that the chunk's timestamps never decrease: see the test of the high half below) */                                          \
+                            const uint64_t delta2 = delta + (more ? (uint64_t)p.dd : 0ull);                                                                    \
+                            bad_m |= lanes((uint32_t)(delta2 >> 32) != 0u) & active_m;                                                                         \
+                            t.stored_delta = (int64_t)delta2;                                                                                                  \
+                            t.stored_ts = d.stored_ts + (uint64_t)m * delta + (more ? delta2 : 0ull);                                                          \
+                            if (more && delta2 != delta) {                                                                                                     \
+                                /* this point's timestamp, and the next one's as the new delta predicts it, go to the */                                       \
+                                /* timestamp tile (a next point that changes the interval again writes its own over */                                         \
+                                /* it); the flush takes the delta from the two */                                                                              \
+                                const uint32_t e = k + m;                                                                                                      \
+                                *reinterpret_cast<uint32_t*>(tile_ts + dec_ts_addr(lane, e)) = (uint32_t)t.stored_ts;                                          \
+                                if (e + 1 < DCH) *reinterpret_cast<uint32_t*>(tile_ts + dec_ts_addr(lane, e + 1)) = (uint32_t)t.stored_ts + (uint32_t)delta2;  \
+                                run_stamps |= (3u << e) & 0xFFFFu;                                                                                             \
+                            }                                                                                                                                  \
+                        }                                                                                                                                      \
+                        bad_m |= more_m & ((lanes(p.changed) & lanes(p.nbits == 0)) | (lanes(o >= 64u) & lanes(p.o3 - off2 > 64u)));                           \
+                        if (more) {                                                                                                                            \
+                            t.nbits = p.nbits;                                                                                                                 \
+                            t.trail = p.trail;                                                                                                                 \
+                            t.val = d.val ^ (p.bits << ((uint32_t)p.trail & 63u));                                                                             \
+                            t.advance(p.o3);                                                                                                                   \
+                            *reinterpret_cast<uint64_t*>(my_vals + (((k + m) ^ swz) << 3)) = t.val;                                                            \
+                            run_slots |= 1u << (k + m);                                                                                                        \
+                        }                                                                                                                                      \
+                        bad_m |= lanes(t.widx >= guard) & active_m;                                                                                            \
+                        d = t;                                                                                                                                 \
+                        k += cnt;                                                                                                                              \
+                        n += cnt;                                                                                                                              \
+                        steps++;                                                                                                                               \
+                        GTSC_WINDOW_READ()                                                                                                                     \
+    }
     // Run skipping (8-word form).  Most points of a sparse stream are the two bits '00': regular cadence,
     // value unchanged.  Walking the 16 slots of a chunk in lock step spends a full parse on each of them in
     // every lane.  Here the lanes go through a chunk at their own pace instead: in one step a lane jumps
@@ -1023,6 +1088,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     // the attempt: the lanes go back to where the chunk began and take the lock-step loop, which knows all
     // of that; nothing the attempt did needs undoing (it lands no top-ups and the tile is rewritten).
     uint32_t run_wait = 0;     // wave-uniform: chunks to sit out before the next attempt
+    bool stamps_mode = false;  // wave-uniform: the run-skipping step that takes interval changes along is in use
+    uint32_t calm = 0;         // chunks in a row in that form without an interval change
     if constexpr (RUN_SKIP) runs[lane] = U4{0u, 0u, 1u, 0u};  // a row without a series: never stored, but looked at
 #ifdef GTSC_RUNSTAT
     uint32_t rs_try = 0, rs_ok = 0, rs_steps = 0, rs_chunks = 0; uint64_t rs_why = 0;
@@ -1050,73 +1117,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                        ((lanes(n + DCH > cap) | lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u)) & active_m) == 0) {
                 const WindowDecoder<FMT> d_at = d;
                 const uint64_t w0_at = w0, w1_at = w1, w2_at = w2;
-                *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
-                uint32_t k = active ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series, or past its end: all)
-                uint32_t steps = 0;
+                uint32_t k = 0, steps = 0;
                 uint64_t bad_m = 0;
-                while (any_lane(k < DCH)) {
-                    // the run: each '00' is a point; a lane that is through the chunk has no room and stays put
-                    const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, d.off);
-                    const uint32_t zeros = (uint32_t)__clz((int)(uint32_t)(hi >> 32));  // 32 when there is no one
-                    const uint32_t room = DCH - k;
-                    const uint32_t m = (zeros >> 1) < room ? (zeros >> 1) : room;
-                    const uint32_t o = d.off + 2u * m;  // <= 63 + 32
-                    // the point after the run, parsed from the words at hand: (w0,w1,w2), or (w1,w2) when
-                    // the run crossed into w1 -- a payload that needs the word after w2 then drops the attempt
-                    WindowDecoder<FMT> t = d;
-                    t.widx = d.widx + (o >> 6);
-                    t.off = o & 63u;
-                    const uint64_t u0 = o >= 64u ? w1 : w0, u1 = o >= 64u ? w2 : w1;
-                    const uint64_t hi2 = WindowDecoder<FMT>::window(u0, u1, t.off);
-                    const uint64_t u2 = w2;
-                    const uint32_t off2 = t.off;
-                    auto lo2 = [u1, u2, off2] { return WindowDecoder<FMT>::window(u1, u2, off2); };
-                    const uint64_t more_m = lanes(m < room);  // lanes with a point to parse
-                    // the timestamp code: '0' in every lane as a rule; an irregular interval somewhere takes the
-                    // general parse for the step (end of stream is the lock-step loop's)
-                    typename WindowDecoder<FMT>::Parsed p;
-                    uint64_t eos_m = 0;
-                    if ((lanes((int64_t)hi2 < 0) & more_m) == 0) {
-                        p = t.template parse<true>(hi2, lo2);
-                    } else {
-                        p = t.template parse<false>(hi2, lo2);
-                        eos_m = lanes(p.eos);
-                    }
-                    bad_m |= more_m & (eos_m | (lanes(p.changed) & lanes(p.nbits == 0)) |
-                                       (lanes(o >= 64u) & lanes(p.o3 - off2 > 64u)));
-                    const bool more = m < room;
-                    const uint32_t cnt = m + (more ? 1u : 0u);
-                    // the run keeps the delta; the point after it may change it (it has to stay within 0..2^32-1,
-                    // so that the chunk's timestamps never decrease: see the test of the high half below)
-                    const uint64_t delta = (uint64_t)d.stored_delta;
-                    const uint64_t delta2 = delta + (more ? (uint64_t)p.dd : 0ull);
-                    bad_m |= lanes((uint32_t)(delta2 >> 32) != 0u) & active_m;
-                    t.stored_delta = (int64_t)delta2;
-                    t.stored_ts = d.stored_ts + (uint64_t)m * delta + (more ? delta2 : 0ull);
-                    if (more) {
-                        t.nbits = p.nbits;
-                        t.trail = p.trail;
-                        t.val = d.val ^ (p.bits << ((uint32_t)p.trail & 63u));
-                        t.advance(p.o3);
-                        *reinterpret_cast<uint64_t*>(my_vals + (((k + m) ^ swz) << 3)) = t.val;
-                        run_slots |= 1u << (k + m);
-                        if (delta2 != delta) {
-                            // the interval changed: this point's timestamp, and the next one's as the new delta
-                            // predicts it, go to the timestamp tile (a next point that changes the interval again
-                            // writes its own over it); the flush takes the delta from the two
-                            const uint32_t e = k + m;
-                            *reinterpret_cast<uint32_t*>(tile_ts + dec_ts_addr(lane, e)) = (uint32_t)t.stored_ts;
-                            if (e + 1 < DCH) *reinterpret_cast<uint32_t*>(tile_ts + dec_ts_addr(lane, e + 1)) = (uint32_t)t.stored_ts + (uint32_t)delta2;
-                            run_stamps |= (3u << e) & 0xFFFFu;
-                        }
-                    }
-                    bad_m |= lanes(t.widx >= guard) & active_m;
-                    d = t;
-                    k += cnt;
-                    n += cnt;
-                    steps++;
-                    GTSC_WINDOW_READ()
-                    if (bad_m) break;
+                uint64_t irregular_m = 0;  // plain steps only: lanes that met a timestamp code other than '0'
+                // One step of every lane, in one of two forms.  The plain form drops the attempt at an interval change
+                // (and the chunk is tried again in the other form, which takes such points along): streams of
+                // perfectly regular cadence keep the shorter step (a lone wave per SIMD: 12 % per chunk).  The form
+                // is the wave's, not the step's: a vote per step on the timestamp codes would cost what it saves.
+                bool stamps = stamps_mode;
+                for (;;) {
+                    *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
+                    k = active ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series, or past its end: all)
+                    steps = 0;
+                    bad_m = 0;
+                    if (stamps) { while (any_lane(k < DCH)) { GTSC_RUN_STEP(true) if (bad_m) break; } }
+                    else        { while (any_lane(k < DCH)) { GTSC_RUN_STEP(false) if (bad_m) break; } }
+                    if (bad_m == 0 || stamps || irregular_m == 0) break;
+                    // an interval changed: once more from the chunk's start, in the form that takes such points along
+                    d = d_at; n = n0; w0 = w0_at; w1 = w1_at; w2 = w2_at;
+                    run_slots = 1u;
+                    stamps = true;
+                    stamps_mode = true;
+                    calm = 0;
+                }
+                if (stamps_mode && bad_m == 0) {
+                    // eight chunks in a row without an interval change: back to the plain step
+                    if (any_lane(run_stamps != 0)) calm = 0;
+                    else if (++calm >= 8) stamps_mode = false;
                 }
                 bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref) & active_m;
 #ifdef GTSC_RUNSTAT
@@ -1325,6 +1352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
 #undef GTSC_RING_LOAD
 #undef GTSC_RING_STORE
 #undef GTSC_POINT
+#undef GTSC_RUN_STEP
     n = active ? n : nfin;
     if (valid) {
         if (n > cap) st |= ST_OVERFLOW;
