@@ -1121,22 +1121,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 uint64_t bad_m = 0;
                 uint64_t irregular_m = 0;  // plain steps only: lanes that met a timestamp code other than '0'
                 // One step of every lane, in one of two forms.  The plain form drops the attempt at an interval change
-                // (and the chunk is tried again in the other form, which takes such points along): streams of
+                // (the following chunks are tried in the other form, which takes such points along): streams of
                 // perfectly regular cadence keep the shorter step (a lone wave per SIMD: 12 % per chunk).  The form
                 // is the wave's, not the step's: a vote per step on the timestamp codes would cost what it saves.
-                bool stamps = stamps_mode;
-                for (;;) {
-                    *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
-                    k = active ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series, or past its end: all)
-                    steps = 0;
-                    bad_m = 0;
-                    if (stamps) { while (any_lane(k < DCH)) { GTSC_RUN_STEP(true) if (bad_m) break; } }
-                    else        { while (any_lane(k < DCH)) { GTSC_RUN_STEP(false) if (bad_m) break; } }
-                    if (bad_m == 0 || stamps || irregular_m == 0) break;
-                    // an interval changed: once more from the chunk's start, in the form that takes such points along
-                    d = d_at; n = n0; w0 = w0_at; w1 = w1_at; w2 = w2_at;
-                    run_slots = 1u;
-                    stamps = true;
+                *reinterpret_cast<uint64_t*>(my_vals + (swz << 3)) = d.val;
+                k = active ? 0u : DCH;  // slots of the chunk the lane has behind it (a lane without a series, or past its end: all)
+                if (stamps_mode) { while (any_lane(k < DCH)) { GTSC_RUN_STEP(true) if (bad_m) break; } }
+                else             { while (any_lane(k < DCH)) { GTSC_RUN_STEP(false) if (bad_m) break; } }
+                if (irregular_m) {
+                    // an interval changed: this chunk is the lock-step loop's, the next ones take such points along
                     stamps_mode = true;
                     calm = 0;
                 }
@@ -1166,8 +1159,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     d = d_at;
                     n = n0;
                     w0 = w0_at; w1 = w1_at; w2 = w2_at;
-                    run_wait = run_backoff;
-                    run_backoff = run_backoff < 64 ? run_backoff * 2 : 64;
+                    if (irregular_m == 0) {  // (after an interval change the next chunk is tried right away, in the other form)
+                        run_wait = run_backoff;
+                        run_backoff = run_backoff < 64 ? run_backoff * 2 : 64;
+                    }
                 }
             }
         }
@@ -1255,8 +1250,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 q1[i] = *reinterpret_cast<const uint64_t*>(tile_val + r * ROW_BYTES + ((s1 ^ rswz) << 3));
                 t0[i] = rr.x + (j0 + 1u) * rr.y;
                 t1[i] = t0[i] + rr.y;
-                if (stamped) {
-                    const uint32_t m0 = rr.w & upto0, m1 = rr.w & upto1;
+            }
+            if (stamped) {  // a pass of its own, so that waves without such rows pay one vote for it
+#pragma unroll
+                for (uint32_t i = 0; i < PASSES; i++) {
+                    const uint32_t r = lrow + i * ROWS_PER_PASS;
+                    const uint32_t marks = runs[r].w;
+                    const uint32_t m0 = marks & upto0, m1 = marks & upto1;
                     const uint32_t e0 = m0 ? 31u - (uint32_t)__clz((int)m0) : 1u, e1 = m1 ? 31u - (uint32_t)__clz((int)m1) : 1u;
                     const uint32_t a0 = *reinterpret_cast<const uint32_t*>(tile_ts + dec_ts_addr(r, e0));
                     const uint32_t b0 = *reinterpret_cast<const uint32_t*>(tile_ts + dec_ts_addr(r, e0 ? e0 - 1u : 0u));
