@@ -98,3 +98,28 @@ def test_bench_command_with_two_ranks(tmp_path):
     for key in ("roofline", "raw_only_frac_of_hbm_peak", "compress_GBps_per_gpu", "decompress_GBps_per_gpu"):
         assert key in j
     assert "cpu_baseline" not in j and "other_workloads" not in j   # single-GPU extras only
+
+
+@pytest.mark.gpu
+def test_rccl_timing_reduction_with_one_rank():
+    """bench.py's only communication is a barrier and a MAX all-reduce of the elapsed time over RCCL (backend "nccl").
+    A one-GPU box cannot hold two RCCL ranks, so this runs the same calls with a world of one, in a child process:
+    the process group comes up on the GPU, the reduction runs on a device tensor and returns the value."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = (
+        "import sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from pygtsc import shard\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "dist.barrier()\n"
+        "assert shard.max_over_ranks(1.25, dist, dev) == 1.25\n"
+        "assert shard.sum_over_ranks(7.0, dist, dev) == 7.0\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl ok')\n" % os.path.join(root, "gorilla-tsc_amd"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
