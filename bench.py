@@ -66,6 +66,11 @@ def make_workload(name, S, P, device, seed):
         start = torch.rand((S, 1), device=device, generator=g, dtype=torch.float64) * 1000
         v = start + torch.cumsum(torch.randn((S, P), device=device, generator=g, dtype=torch.float64) * 0.05, dim=1)
         v = torch.round(v * 100) / 100
+    elif name == "counter":
+        # integer-valued counter that grows by 0..4 per step (one step in five leaves it unchanged)
+        cadence = 1000
+        start = torch.randint(0, 1000, (S, 1), device=device, generator=g).double()
+        v = start + torch.cumsum(torch.randint(0, 5, (S, P), device=device, generator=g).double(), dim=1)
     elif name == "random_walk":
         cadence = 1000
         v = 100.0 + torch.cumsum(torch.randn((S, P), device=device, generator=g, dtype=torch.float64), dim=1)
@@ -170,7 +175,9 @@ def other_workloads(measure, ctx):
                                           "decompress": round(m["raw_bytes"] / m["dec_ms"] / 1e6 / HBM_PEAK_GBPS, 4)},
             "roofline_frac": round(m["algo_bytes"] / slow / 1e6 / HBM_PEAK_GBPS, 4),
             "encode_ms": round(m["enc_ms"], 4), "decode_ms": round(m["dec_ms"], 4),
+            "encode_ms_spread": m["enc_spread"], "decode_ms_spread": m["dec_spread"],
             "compressed_bits_per_point": round(64.0 * m["total_words"] / (S * P), 3),
+            "tunables_set_by_this_caller": m["tunables"], "kernels_dispatched": m["kernels"],
         }
         torch.cuda.empty_cache()
     # batches too small to fill the GPU: the reference's own block, and the reference benchmark's data
@@ -332,13 +339,31 @@ def main():
             val2 = torch.zeros_like(val)
         npts = torch.zeros(S, dtype=torch.int64, device=device)
 
+        ctx_dispatch = {}
+
         def encode():
             ctx.encode_device(block, ts, val, out, nw, uniform_npoints=P, uniform_slot_words=slot, fmt=fmt)
+            ctx_dispatch["encode"] = ctx.last_dispatch()
 
         def decode():
             ctx.decode_device(out, ts2, val2, npts, S, uniform_slot_words=slot, in_nwords=nw, uniform_capacity=P, fmt=fmt)
+            ctx_dispatch["decode"] = ctx.last_dispatch()
 
+        # The library decides from the batch alone; what a caller knows about its data it says through tunables.  This
+        # caller compresses the batch once, looks at the density, and says: dense streams (the lane-per-series
+        # decompressor's 16-word rings), or sparse ones (the lane-per-series compressor for many long blocks).
         torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            encode()
+        try:
+            ctx.sync()
+        except G.GtscError:
+            if not args.no_verify:
+                raise
+        bits_per_point = 64.0 * int(nw.sum()) / max(S * P, 1)
+        tun = {"decode_ring": 16 if bits_per_point > 40 else 8, "sparse_hint": 1 if bits_per_point <= 16 else 0}
+        ctx.set_decode_ring(tun["decode_ring"])
+        ctx.set_tunable(G.TUNE_SPARSE_HINT, tun["sparse_hint"])
         with torch.cuda.stream(stream):
             for _ in range(warmup):
                 encode()
@@ -373,11 +398,15 @@ def main():
         if timed_by_host and dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        enc_all = [e[0].elapsed_time(e[1]) for e in ev]
+        dec_all = [e[1].elapsed_time(e[2]) for e in ev]
+        enc_ms, dec_ms = float(np.mean(enc_all)), float(np.mean(dec_all))
+        spread = lambda x: {"min": round(float(np.min(x)), 4), "median": round(float(np.median(x)), 4), "max": round(float(np.max(x)), 4)}  # noqa: E731
         raw = 16.0 * S * P
         algo = raw + 8.0 * total_words + 16.0 * S  # raw points + compressed words + per-series block_ts and length
-        r = {"elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "raw_bytes": raw, "algo_bytes": algo, "total_words": total_words}
+        r = {"elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "raw_bytes": raw, "algo_bytes": algo, "total_words": total_words,
+             "enc_spread": spread(enc_all), "dec_spread": spread(dec_all), "tunables": tun,
+             "kernels": {"encode": ctx_dispatch["encode"], "decode": ctx_dispatch["decode"]}}
         if keep_inputs:
             r["inputs"] = (block, ts, val)
         return r
@@ -420,6 +449,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(dom_ms, 4),
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
+            # per-launch spread of the HIP-event times over the timed steps (avg_launch_ms is their mean)
+            "encode_ms_spread": m["enc_spread"], "decode_ms_spread": m["dec_spread"],
+            "tunables_set_by_this_caller": m["tunables"], "kernels_dispatched": m["kernels"],
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -78,9 +79,6 @@ constexpr size_t FLAG_BLOCK_BYTES = 64;
 // Above this many compressed bits per point the decoder's 16-word input rings pay (measured cross-over:
 // gauges at 5 bits lose 8 %, drifting gauges at 47 bits gain 3 %, random walks and random doubles 10 %).
 constexpr uint64_t DENSE_BITS_PER_POINT = 40;
-// Up to this many compressed bits per point a stream counts as sparse: most of its points are unchanged
-// values at a regular interval, which the lane-per-series kernels skip in runs.
-constexpr uint64_t SPARSE_BITS_PER_POINT = 16;
 
 // The host pipeline has three streams -- all copy-ins, all kernels, all copy-outs, each back to back -- and
 // NSTAGE sets of device buffers that chunks take in turn, tied together by events.  With the context's own
@@ -92,10 +90,7 @@ struct gtsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // the one launches go to
-    // device block of FLAG_BLOCK_BYTES: word 0 = OR of status bits raised since the last sync; at byte 8 five
-    // 64-bit counts of a sample of the waves since then: the decoder's compressed words read, points stored, and
-    // the wave-per-block kernel's steps (low half) and the points they found (high half); the compressor's words
-    // written and points coded
+    // device block of FLAG_BLOCK_BYTES: word 0 = OR of status bits raised since the last sync
     uint32_t* d_flags = nullptr;
     uint32_t* h_flags = nullptr;    // pinned mirror
     // The host entry points raise their status bits in a block of their own (the second
@@ -103,15 +98,12 @@ struct gtsc_ctx {
     // points, whose flags and counts wait for gtsc_sync() untouched.
     uint32_t* d_flags_host = nullptr;
     uint32_t* h_flags_host = nullptr;
-    // third block of the device allocation: counts of long series, one word per user
-    // (the device entry point, the two stages of the host pipeline)
-    uint64_t* d_long_count = nullptr;
+    // then the decode plans (what a batch of images looks like, worked out on the device before its kernels
+    // start): one for the device entry point, one per stage of the host pipeline
+    DecodePlan* d_plans = nullptr;
     uint64_t* noalloc_scratch = nullptr;  // this device's copy of the library's static scratch array
-    bool deep_ring = false;         // the last decoded batches were dense: decode with the 16-word input rings
-    bool enc_sparse = false;        // the last compressed batches came to a few bits per point
-    bool dec_sparse = false;        // so did the last decompressed ones
-    int forced_ring = 0;            // gtsc_set_decode_ring: 0 = by density, 8 or 16 = always that form
-    uint64_t long_blocks_max = 0;   // batches of up to this many long blocks go to the wave-per-block decoder (0: the kernels' own figure)
+    Tunables tun;                   // gtsc_set_tunable; nothing the context has coded before enters a choice of kernel
+    uint32_t last_dispatch = 0;     // gtsc_last_dispatch: the kernels the last device call enqueued
     DeviceBuf scan_scratch;
     // predictor of the value codec: 0 = last value, else DFCM with tables of dfcm_mask + 1 entries
     int predictor = GTSC_PRED_LAST;
@@ -144,6 +136,54 @@ int check_ctx(gtsc_ctx* ctx)
 {
     if (!ctx) return fail(GTSC_ERR_ARG, "ctx is NULL");
     return GTSC_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// the tunables by number (GTSC_TUNE_* in gtsc.h), with the environment variable that presets each
+struct TunableSlot { int id; const char* env; uint64_t Tunables::* u64; uint32_t Tunables::* u32; };
+const TunableSlot TUNABLES[] = {
+    {GTSC_TUNE_LONG_POINTS, "GTSC_LONG_POINTS", &Tunables::long_points, nullptr},
+    {GTSC_TUNE_VLONG_POINTS, "GTSC_VLONG_POINTS", &Tunables::vlong_points, nullptr},
+    {GTSC_TUNE_WAVE_DECODE_MAX, "GTSC_LONG_DECODE_MAX", &Tunables::wave_decode_max, nullptr},
+    {GTSC_TUNE_WAVE_DECODE_MAX_DENSE, "GTSC_LONG_DECODE_MAX_DENSE", &Tunables::wave_decode_max_dense, nullptr},
+    {GTSC_TUNE_WG_DECODE_MAX, "GTSC_WG_DECODE_MAX", &Tunables::wg_decode_max, nullptr},
+    {GTSC_TUNE_WG_DECODE_VLONG_MAX, "GTSC_WG_DECODE_VLONG_MAX", &Tunables::wg_decode_vlong_max, nullptr},
+    {GTSC_TUNE_WG_DENSE_BITS, "GTSC_WG_DENSE_BITS", nullptr, &Tunables::wg_dense_bits},
+    {GTSC_TUNE_DENSE_BITS, "GTSC_DENSE_BITS", nullptr, &Tunables::dense_bits},
+    {GTSC_TUNE_SPARSE_ENCODE_MIN, "GTSC_SPARSE_TILED_MIN", &Tunables::sparse_encode_min, nullptr},
+    {GTSC_TUNE_COOP_ENCODE_MAX, "GTSC_COOP_MAX", &Tunables::coop_encode_max, nullptr},
+    {GTSC_TUNE_SPARSE_HINT, "GTSC_SPARSE_HINT", nullptr, &Tunables::sparse_hint},
+    {GTSC_TUNE_DECODE_RING, "GTSC_RING", nullptr, &Tunables::decode_ring},
+    {GTSC_TUNE_RUN_SKIP, "GTSC_RUN_SKIP", nullptr, &Tunables::run_skip},
+    {GTSC_TUNE_DIRECT_KERNELS, "GTSC_DIRECT", nullptr, &Tunables::direct},
+};
+
+void set_tunable(Tunables& t, const TunableSlot& slot, uint64_t v)
+{
+    if (slot.u64) t.*slot.u64 = v;
+    else t.*slot.u32 = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+}
+
+bool tunable_value_ok(int id, uint64_t v)
+{
+    if (id == GTSC_TUNE_DECODE_RING) return v == 0 || v == 8 || v == 16;
+    if (id == GTSC_TUNE_SPARSE_HINT || id == GTSC_TUNE_RUN_SKIP || id == GTSC_TUNE_DIRECT_KERNELS) return v <= 1;
+    return true;
+}
+
+void tunables_from_environment(Tunables& t)
+{
+    for (const TunableSlot& slot : TUNABLES) {
+        const char* e = getenv(slot.env);
+        if (!e || !*e) continue;
+        const uint64_t v = strtoull(e, nullptr, 10);
+        if (tunable_value_ok(slot.id, v)) set_tunable(t, slot, v);
+    }
+    const char* k = getenv("GTSC_KERNEL");   // (the older spelling of GTSC_DIRECT=1)
+    if (k && !strcmp(k, "direct")) t.direct = 1;
 }
 
 }  // namespace
@@ -196,13 +236,15 @@ int gtsc_create(int device_id, gtsc_ctx** out)
     if (!c) return fail(GTSC_ERR_ARG, "out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 3 * FLAG_BLOCK_BYTES);
-    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 3 * FLAG_BLOCK_BYTES);
+    constexpr size_t DEV_BYTES = 2 * FLAG_BLOCK_BYTES + (1 + NSTAGE) * sizeof(DecodePlan);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, DEV_BYTES);
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, DEV_BYTES);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 2 * FLAG_BLOCK_BYTES, hipHostMallocDefault);
     if (e == hipSuccess) {
         c->d_flags_host = c->d_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
         c->h_flags_host = c->h_flags + FLAG_BLOCK_BYTES / sizeof(uint32_t);
-        c->d_long_count = reinterpret_cast<uint64_t*>(c->d_flags + 2 * FLAG_BLOCK_BYTES / sizeof(uint32_t));
+        c->d_plans = reinterpret_cast<DecodePlan*>(c->d_flags + 2 * FLAG_BLOCK_BYTES / sizeof(uint32_t));
+        tunables_from_environment(c->tun);
     }
     if (e == hipSuccess) e = noalloc_scratch_of_current_device(&c->noalloc_scratch);
     if (e != hipSuccess) {
@@ -258,10 +300,45 @@ int gtsc_set_predictor(gtsc_ctx* c, int predictor, int table_size)
 
 int gtsc_set_decode_ring(gtsc_ctx* c, int ring_words)
 {
+    return gtsc_set_tunable(c, GTSC_TUNE_DECODE_RING, ring_words < 0 ? ~0ull : (uint64_t)ring_words);
+}
+
+int gtsc_set_tunable(gtsc_ctx* c, int which, uint64_t value)
+{
     if (int rc = check_ctx(c)) return rc;
-    if (ring_words != 0 && ring_words != 8 && ring_words != 16) return fail(GTSC_ERR_ARG, "ring_words must be 0, 8 or 16");
-    c->forced_ring = ring_words;
-    if (ring_words) c->deep_ring = ring_words == 16;
+    for (const TunableSlot& slot : TUNABLES) {
+        if (slot.id != which) continue;
+        if (!tunable_value_ok(which, value)) return fail(GTSC_ERR_ARG, "tunable %d does not take the value %llu", which, (unsigned long long)value);
+        set_tunable(c->tun, slot, value);
+        return GTSC_OK;
+    }
+    return fail(GTSC_ERR_ARG, "unknown tunable %d", which);
+}
+
+int gtsc_get_tunable(gtsc_ctx* c, int which, uint64_t* value)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!value) return fail(GTSC_ERR_ARG, "value out-pointer is NULL");
+    for (const TunableSlot& slot : TUNABLES) {
+        if (slot.id != which) continue;
+        *value = slot.u64 ? c->tun.*slot.u64 : (uint64_t)(c->tun.*slot.u32);
+        return GTSC_OK;
+    }
+    return fail(GTSC_ERR_ARG, "unknown tunable %d", which);
+}
+
+int gtsc_last_dispatch(gtsc_ctx* c, uint32_t* kernels, uint64_t plan[6])
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (kernels) *kernels = c->last_dispatch;
+    if (plan && !(c->last_dispatch & DISPATCH_PLAN)) {
+        for (int i = 0; i < 6; i++) plan[i] = 0;   // the last call needed no plan
+    } else if (plan) {
+        // what the device made of the last gtsc_decode_device batch (waits for the context's stream)
+        DeviceGuard g(c->device);
+        HIP_TRY(hipMemcpyAsync(plan, c->d_plans, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return GTSC_OK;
 }
 
@@ -280,21 +357,6 @@ int gtsc_sync(gtsc_ctx* c)
     HIP_TRY(hipMemsetAsync(c->d_flags, 0, FLAG_BLOCK_BYTES, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t f = *c->h_flags;
-    {   // how dense were the streams decoded since the last sync: the next decodes use the ring that suits them
-        const uint64_t* counts = reinterpret_cast<const uint64_t*>(c->h_flags) + 1;
-        if (counts[1] && !c->forced_ring) c->deep_ring = counts[0] * 64 > counts[1] * DENSE_BITS_PER_POINT;
-        if (counts[1]) c->dec_sparse = counts[0] * 64 <= counts[1] * SPARSE_BITS_PER_POINT;
-        if (counts[4]) c->enc_sparse = counts[3] * 64 <= counts[4] * SPARSE_BITS_PER_POINT;
-        // and how many points a step of the wave-per-block decoder found: batches of about a thousand long
-        // blocks per point are where it breaks even with the lane-per-series kernel -- four hundred per point
-        // on sparse streams, which that kernel decodes a run of unchanged points at a time (7,200-point gauges:
-        // 1.25 ms whatever the count up to 49,152 blocks, against 0.62 ms for 4,096 and 1.45 ms for 12,288)
-        const uint64_t steps = counts[2] & 0xFFFFFFFFull, found = counts[2] >> 32;
-        if (steps) {
-            const uint64_t m = (c->dec_sparse ? 400 : 1024) * found / steps;
-            c->long_blocks_max = m < 2048 ? 2048 : m > 20480 ? 20480 : m;
-        }
-    }
     if (f & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", f);
     if (f & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series overflowed their output slot");
     return GTSC_OK;
@@ -319,9 +381,10 @@ int gtsc_encode_device_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t ns
     DeviceGuard g(c->device);
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
+    c->last_dispatch = 0;
     EncodeArgs a{nseries, block_ts, ts, val, Layout{pt_off, uniform_npoints}, out_words, Layout{out_off, uniform_slot_words},
                  out_nwords, status, c->d_flags, out_nbits, (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, tables, c->dfcm_mask, 0u, ~0ull, 0u,
-                 c->enc_sparse ? 1u : 0u, reinterpret_cast<uint64_t*>(c->d_flags) + 1};
+                 c->tun, &c->last_dispatch};
     HIP_TRY(launch_encode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -378,9 +441,9 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     DeviceGuard g(c->device);
     int64_t* tables = nullptr;
     HIP_TRY(dfcm_prepare(c, 0, nseries, c->stream, &tables));
+    c->last_dispatch = 0;
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
-                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, c->forced_ring == 16 ? 2u : (c->deep_ring ? 1u : 0u),
-                 reinterpret_cast<uint64_t*>(c->d_flags) + 1, ~0ull, nullptr, 0, c->d_long_count, c->long_blocks_max, 0u};
+                 out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, ~0ull, nullptr, c->d_plans, 0u, 0u, c->tun, &c->last_dispatch};
     HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
@@ -425,6 +488,19 @@ int gtsc_compact_device_noalloc(gtsc_ctx* c, uint64_t nseries, const uint64_t* s
 // ------------------------------------------------------------------------
 // Host-memory entry points: chunked, NSTAGE streams taking turns.
 // ------------------------------------------------------------------------
+int gtsc_host_pipeline_idle(gtsc_ctx* c)
+{
+    if (int rc = check_ctx(c)) return rc;
+    DeviceGuard g(c->device);
+    for (hipStream_t q : {c->copy_in, c->work, c->copy_out}) {
+        if (!q) continue;
+        const hipError_t e = hipStreamQuery(q);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) return fail(GTSC_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    }
+    return 1;
+}
+
 void* gtsc_host_alloc(size_t bytes)
 {
     void* p = nullptr;
@@ -502,7 +578,28 @@ int ensure_stage_streams(gtsc_ctx* c)
     return GTSC_OK;
 }
 
-// status bits raised by the host pipeline (both of its streams are idle when this is called)
+// Every way out of a host entry point goes through this: whatever the pipeline still has in flight -- copies out of
+// the caller's input arrays, copies into its output arrays -- is waited for before the call returns, also when it
+// returns an error half way (a buffer that could not grow, a failed launch), so that the caller may free or reuse
+// its arrays whatever the return code.
+struct PipelineDrain {
+    gtsc_ctx* c;
+    ~PipelineDrain()
+    {
+        for (hipStream_t q : {c->copy_in, c->work, c->copy_out})
+            if (q) (void)hipStreamSynchronize(q);
+    }
+};
+
+// GTSC_TEST_FAIL_CHUNK=k makes the host pipeline fail (as if a staging buffer could not grow) when it stages its
+// k-th chunk: for the test of the error path.
+bool injected_failure(size_t chunk)
+{
+    static const long k = [] { const char* e = getenv("GTSC_TEST_FAIL_CHUNK"); return e && *e ? strtol(e, nullptr, 10) : -1L; }();
+    return k >= 0 && (size_t)k == chunk;
+}
+
+// status bits raised by the host pipeline (its streams are idle when this is called)
 int read_flags(gtsc_ctx* c, hipStream_t stream, uint32_t* out)
 {
     HIP_TRY(hipMemcpyAsync(c->h_flags_host, c->d_flags_host, FLAG_BLOCK_BYTES, hipMemcpyDeviceToHost, stream));
@@ -532,6 +629,7 @@ int gtsc_encode_host_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nser
     if ((!ts || !val) && (pt_off || uniform_npoints)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
     DeviceGuard g(c->device);
     if (int rc = ensure_stage_streams(c)) return rc;
+    PipelineDrain drain{c};
 
     const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_npoints, true);
     // Copy-in runs two chunks ahead of the kernels.  On the work stream a chunk's kernels are followed by
@@ -544,6 +642,7 @@ int gtsc_encode_host_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nser
         auto& st = c->stage[b];
         if (used[b]) HIP_TRY(hipEventSynchronize(st.drained));  // the stage's previous chunk has left its buffers
         used[b] = true;
+        if (injected_failure(k)) return fail(GTSC_ERR_HIP, "staging chunk %zu: injected failure", k);
         Geometry& g = geo[b];
         g.s0 = chunks[k].s0; g.s1 = chunks[k].s1; g.ns = g.s1 - g.s0;
         g.p0 = pt_off ? pt_off[g.s0] : g.s0 * uniform_npoints;
@@ -601,7 +700,7 @@ int gtsc_encode_host_ex(gtsc_ctx* c, int format, uint32_t options, uint64_t nser
         EncodeArgs a{g.ns, st.block_ts.as<int64_t>(), st.ts.as<int64_t>(), st.val.as<uint64_t>(),
                      Layout{g.d_pt_off, uniform_npoints}, st.slots.as<uint64_t>(), Layout{g.d_slot_off, g.uniform_slot},
                      st.nwords.as<uint64_t>(), nullptr, c->d_flags_host, out_nbits ? st.nbits.as<uint64_t>() : nullptr,
-                     (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, nullptr, c->dfcm_mask, 0u, ~0ull, 0u, 0u, nullptr};
+                     (options & GTSC_ENC_NO_CLOSE) ? 1u : 0u, nullptr, c->dfcm_mask, 0u, ~0ull, 0u, c->tun, nullptr};
         HIP_TRY(dfcm_prepare(c, 1 + b, g.ns, c->work, &a.dfcm_tables));
         HIP_TRY(launch_encode(a, format, c->work));
         HIP_TRY(launch_exclusive_scan(st.nwords.as<uint64_t>(), g.ns, st.coff.as<uint64_t>(), c->scan_scratch.as<uint64_t>(), c->work));
@@ -646,8 +745,11 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
     if (nseries == 0) return GTSC_OK;
     if (!words || !in_off || !out_npoints) return fail(GTSC_ERR_ARG, "words/in_off/out_npoints must not be NULL");
     if ((!ts || !val) && (pt_off || uniform_capacity)) return fail(GTSC_ERR_ARG, "ts/val must not be NULL");
+    if (c->predictor != GTSC_PRED_LAST && format != GTSC_FMT_V2)
+        return fail(GTSC_ERR_ARG, "only the 2.x format takes a predictor");
     DeviceGuard g(c->device);
     if (int rc = ensure_stage_streams(c)) return rc;
+    PipelineDrain drain{c};
 
     const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_capacity, false);
     bool used[NSTAGE] = {};
@@ -656,6 +758,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         auto& st = c->stage[b];
         if (used[b]) HIP_TRY(hipEventSynchronize(st.drained));  // the stage's previous chunk has left its buffers
         used[b] = true;
+        if (injected_failure(k)) return fail(GTSC_ERR_HIP, "staging chunk %zu: injected failure", k);
         const uint64_t s0 = chunks[k].s0, s1 = chunks[k].s1, ns = s1 - s0;
         const uint64_t w0 = in_off[s0], nw = in_off[s1] - w0;
         const uint64_t p0 = pt_off ? pt_off[s0] : s0 * uniform_capacity;
@@ -684,10 +787,10 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         HIP_TRY(hipStreamWaitEvent(c->work, st.copied_in, 0));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
-                     st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u,
-                     (c->forced_ring ? (c->forced_ring == 16 ? 2u : 0u) : (nw * 64 > np * DENSE_BITS_PER_POINT ? 1u : 0u)) /* the host form knows the density */,
-                     nullptr,
-                     ~0ull, nullptr, 0, c->d_long_count + 1, c->long_blocks_max, 0u};
+                     st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u, ~0ull, nullptr, c->d_plans + 1 + b, 0u, 0u,
+                     c->tun, nullptr};
+        // the host form knows the chunk's density: no need to let the device choose the ring
+        if (a.tun.decode_ring == 0) a.tun.decode_ring = nw * 64 > np * DENSE_BITS_PER_POINT ? 16u : 8u;
         HIP_TRY(dfcm_prepare(c, 1 + b, ns, c->work, &a.dfcm_tables));
         HIP_TRY(launch_decode(a, format, c->work));
         HIP_TRY(hipEventRecord(st.coded, c->work));

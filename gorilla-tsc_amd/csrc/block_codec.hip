@@ -299,10 +299,6 @@ __device__ __forceinline__ void encode_block(const EncodeArgs& a, uint64_t s, ui
         stage[0] = 0;
         // a block beyond the point limit was coded up to the limit: reported, not silent
         const uint32_t st = (nwords > w.cap || np64 > BLOCK_MAX_POINTS) ? ST_OVERFLOW : 0u;
-        if (a.stats && (s & 63u) == 0) {  // how dense the streams are: a sample for the library's choice of kernel
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, (unsigned long long)nwords);
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 4, (unsigned long long)np64);
-        }
         a.out_nwords[s] = nwords;
         if (a.out_nbits) a.out_nbits[s] = nbits;
         if (a.status) a.status[s] = st;
@@ -564,27 +560,6 @@ struct BlockDecodeLds {
     uint32_t qwin[QUEUE_SLOTS];   // the value window in force there: significant bits | (trailing zeros & 127) << 8
 };
 
-// inclusive prefix sum / xor of 64-bit values over the wave
-template <bool XOR>
-__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v)
-{
-#define GTSC_SCAN_STEP(CTRL, RM)                                                               \
-    {                                                                                          \
-        const uint32_t lo_ = dpp_move<CTRL, RM>(0u, (uint32_t)v);                              \
-        const uint32_t hi_ = dpp_move<CTRL, RM>(0u, (uint32_t)(v >> 32));                      \
-        const uint64_t o_ = ((uint64_t)hi_ << 32) | lo_;                                       \
-        v = XOR ? (v ^ o_) : (v + o_);                                                         \
-    }
-    GTSC_SCAN_STEP(0x111, 0xF)
-    GTSC_SCAN_STEP(0x112, 0xF)
-    GTSC_SCAN_STEP(0x114, 0xF)
-    GTSC_SCAN_STEP(0x118, 0xF)
-    GTSC_SCAN_STEP(0x142, 0xA)
-    GTSC_SCAN_STEP(0x143, 0xC)
-#undef GTSC_SCAN_STEP
-    return v;
-}
-
 template <int FMT>
 __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, BlockDecodeLds& lds, uint32_t lane)
 {
@@ -646,10 +621,8 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
     bool stop = finished || serial;   // the walk has met the end of the stream or something for the serial decoder
     bool clean_end = finished;
 
-    uint32_t steps = 0;               // for the library's figure of how the kernel fares on these streams
     while (!(stop && qn == 0)) {
         if (!stop) {
-            steps++;
             // ---- one step: 64 candidate starts.  Sparse streams: the 64 bit positions from cur on.
             // Streams of equal-sized points: the positions cur + j * stride -- while the points that
             // follow have the predicted form, all 64 candidates are real starts.
@@ -920,14 +893,6 @@ __device__ __forceinline__ void decode_block(const DecodeArgs& a, uint64_t s, Bl
         a.out_npoints[s] = n;
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
-        // what the block read and produced, for the library's density figure (one block in 64 reports, as
-        // one wave in 64 of the lane-per-series kernel does)
-        if (a.stats && (s & 63u) == 0) {
-            const uint64_t words = pos >> 6;
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats), (unsigned long long)(words < nw ? words : nw));
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 1, (unsigned long long)(n < cap ? n : cap));
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 2, (unsigned long long)steps | ((unsigned long long)(n < cap ? n : cap) << 32));
-        }
     }
     wave_sync();
 }
@@ -937,9 +902,8 @@ __global__ __launch_bounds__(64) void decode_block_kernel(DecodeArgs a, uint32_t
 {
     __shared__ BlockDecodeLds lds;
     const uint32_t lane = threadIdx.x;
-    if (a.long_count && *a.long_count > a.long_max_series) return;   // too many long blocks: the lane-per-series kernel has them
     const uint64_t cand = blockIdx.x + (uint64_t)lane * gridDim.x;
-    const bool mine = lane < per_wave && cand < a.nseries && a.pts.size(cand) >= a.long_threshold;
+    const bool mine = lane < per_wave && cand < a.nseries && block_owner(a, cand) == OWNER_WAVE;
     uint64_t todo = lanes(mine);
     while (todo) {
         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
@@ -948,14 +912,31 @@ __global__ __launch_bounds__(64) void decode_block_kernel(DecodeArgs a, uint32_t
     }
 }
 
-// How many series of the batch are "long" (capacity of at least long_threshold points): both decode
-// kernels read the count and agree on who takes them.
-__global__ __launch_bounds__(256) void count_long_kernel(uint64_t nseries, Layout pts, uint64_t long_threshold, uint64_t* count)
+// The plan of a batch of images (DecodePlan): how many series are long and very long, how dense the long ones'
+// images are, and how dense every 64th image of the batch is.  All decompressors of the batch read it.
+__global__ __launch_bounds__(256) void plan_decode_kernel(DecodeArgs a, DecodePlan* plan)
 {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool is_long = s < nseries && pts.size(s) >= long_threshold;
-    const uint32_t c = (uint32_t)__builtin_popcountll(lanes(is_long));
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(reinterpret_cast<unsigned long long*>(count), (unsigned long long)c);
+    const bool in = s < a.nseries;
+    const uint64_t cap = in ? a.pts.size(s) : 0;
+    const bool is_long = in && cap >= a.tun.long_points, is_vlong = in && cap >= a.tun.vlong_points;
+    const bool sampled = in && (s & 63u) == 0;
+    const uint64_t nw = (is_long || sampled) ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
+    const uint64_t ml = lanes(is_long), mv = lanes(is_vlong);
+    unsigned long long* const out = reinterpret_cast<unsigned long long*>(plan);
+    if (ml) {
+        const uint64_t w = wave_inclusive_scan64<false>(is_long ? nw : 0ull), c = wave_inclusive_scan64<false>(is_long ? cap : 0ull);
+        if ((threadIdx.x & 63) == 63) {
+            atomicAdd(out + 0, (unsigned long long)__builtin_popcountll(ml));
+            atomicAdd(out + 1, (unsigned long long)__builtin_popcountll(mv));
+            atomicAdd(out + 2, (unsigned long long)w);
+            atomicAdd(out + 3, (unsigned long long)c);
+        }
+    }
+    if (sampled && (nw | cap)) {   // (one lane per wave)
+        atomicAdd(out + 4, (unsigned long long)nw);
+        atomicAdd(out + 5, (unsigned long long)cap);
+    }
 }
 
 }  // namespace
@@ -967,13 +948,14 @@ hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t str
     // workgroup keeps a compute unit busy, so the form pays up to about one and a half blocks per unit (a lone
     // 100,000-point block: 0.25 ms against 0.95; 1,024 of them: 1.0 ms either way; 7,200-point blocks break even
     // at about 400).
-    static const uint64_t coop_max = [] { const char* e = getenv("GTSC_COOP_MAX"); return e ? strtoull(e, nullptr, 10) : 384ull; }();
-    if (a.nseries <= coop_max) {
+    if (a.nseries <= a.tun.coop_encode_max) {
+        if (a.dispatch) *a.dispatch |= DISPATCH_COOP;
         if (format == FMT_V2) hipLaunchKernelGGL(encode_block_coop_kernel<FMT_V2>, dim3((uint32_t)a.nseries), dim3(64 * COOP_WAVES), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_block_coop_kernel<FMT_V1>, dim3((uint32_t)a.nseries), dim3(64 * COOP_WAVES), 0, stream, a);
         return hipGetLastError();
     }
     // enough waves to fill the machine several times over when there are that many series
+    if (a.dispatch) *a.dispatch |= DISPATCH_WAVE;
     uint64_t per_wave = a.nseries / 8192;
     per_wave = per_wave < 1 ? 1 : per_wave > 64 ? 64 : per_wave;
     const uint32_t grid = (uint32_t)((a.nseries + per_wave - 1) / per_wave);
@@ -986,18 +968,19 @@ hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t str
 
 namespace gtsc {
 
-hipError_t launch_count_long(uint64_t nseries, Layout pts, uint64_t long_threshold, uint64_t* count, hipStream_t stream)
+hipError_t launch_decode_plan(const DecodeArgs& a, hipStream_t stream)
 {
-    if (hipError_t e = hipMemsetAsync(count, 0, sizeof(uint64_t), stream)) return e;
-    if (nseries == 0) return hipSuccess;
-    hipLaunchKernelGGL(count_long_kernel, dim3((uint32_t)((nseries + 255) / 256)), dim3(256), 0, stream, nseries, pts,
-                       long_threshold, count);
+    if (hipError_t e = hipMemsetAsync(a.plan_buf, 0, sizeof(DecodePlan), stream)) return e;
+    if (a.nseries == 0) return hipSuccess;
+    if (a.dispatch) *a.dispatch |= DISPATCH_PLAN;
+    hipLaunchKernelGGL(plan_decode_kernel, dim3((uint32_t)((a.nseries + 255) / 256)), dim3(256), 0, stream, a, a.plan_buf);
     return hipGetLastError();
 }
 
 hipError_t launch_decode_blocks(const DecodeArgs& a, int format, hipStream_t stream)
 {
     if (a.nseries == 0) return hipSuccess;
+    if (a.dispatch) *a.dispatch |= DISPATCH_WAVE;
     uint64_t per_wave = a.nseries / 8192;
     per_wave = per_wave < 1 ? 1 : per_wave > 64 ? 64 : per_wave;
     const uint32_t grid = (uint32_t)((a.nseries + per_wave - 1) / per_wave);

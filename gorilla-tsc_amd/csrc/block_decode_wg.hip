@@ -1,0 +1,797 @@
+// Workgroup-per-block form of the Gorilla decompressor on gfx950, for batches of few long blocks.
+//
+// Where a point starts is only known from the points before it (G/GorillaDecompressor.java:74-112,
+// G/ValueDecompressor.java:32-54; G/ = src/main/java/fi/iki/yak/ts/compression/gorilla/ in the reference
+// tree), so the chain of start positions is the serial part of a block.  A lone wavefront issues an
+// instruction every five cycles at best: doing everything else in the same wave (wave-per-block kernel,
+// block_codec.hip) leaves a long block slower than one host thread.  Here a block has a workgroup, and
+// its waves split the work by kind:
+//
+//   * classifier waves work out, for EVERY bit position of the next 4,096 bits of the image, what a point
+//     starting there would look like -- timestamp bucket, kind of value code, length apart from the
+//     window bits of a '10' code, the window a '11' code declares, the run of '00' points that begins
+//     there -- and leave one word per position in LDS.  None of that depends on what came before;
+//   * one walker wave follows the chain through those words: a hop is a lane read and an add (a run of
+//     unchanged points is one hop); where the points have the same length it tests 64 starts a stride
+//     apart with one gathered read.  It queues the starts with the value window in force at each;
+//   * emitter waves (the classifiers, once they are done) parse 64 queued points each, and prefix
+//     sums / a prefix XOR over the wave and then over the batches turn delta-of-deltas and XOR payloads
+//     into timestamps and values, stored as 512-byte runs.
+//
+// The three run as a pipeline over regions of 4,096 bit positions, one step ("tick") per region, with
+// workgroup barriers in between: in tick k the walker is in region k while the others classify region
+// k + 1 and emit what the walker queued in region k - 1.
+//
+// Anything out of the ordinary -- end of the image inside a point, a reused window that was never
+// defined, a decoded timestamp of zero (which makes the reference read the next point as a "first"
+// one), more points than the caller's capacity -- hands the block to one lane, which walks on from the
+// last point stored with the serial decoder of the lane-per-series kernels, so that counts, status
+// words and the order in which the reference's reads meet a problem are the same.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "codec_device.hpp"
+#include "kernels.hpp"
+#include "wave_util.hpp"
+
+namespace gtsc {
+
+namespace {
+
+constexpr uint32_t RPOS = 4096;            // bit positions per region
+constexpr uint32_t RW = RPOS / 64;         // image words per region
+constexpr uint32_t RINGW = 8 * RW;         // image words staged in LDS (circular)
+constexpr uint32_t QCAP = RPOS / 2;        // a region holds at most that many points ('00' each)
+constexpr uint32_t MAXB = QCAP / 64;       // batches of 64 queued points per region
+
+// What a point starting at a bit position looks like ("hop word"):
+//   bits 0..7    how far the chain hops from here: the point's length without the payload of a reused window
+//                ('10' codes: + window bits) -- or, where a run of '00' points (regular interval, unchanged
+//                value) begins, the bits of the whole run as far as it stays inside the position's row of 64
+//   bit 9        such a run;  bit 10 / 11: the value code is '10' / '11';  bit 12: the position holds the end marker
+//   bits 13..19  significant bits, bits 20..26 trailing zeros (7 bits, signed) of a '11' code's window
+constexpr uint32_t HW_RUN = 0x200u, HW_T1 = 0x400u, HW_T2 = 0x800u, HW_EOS = 0x1000u;
+constexpr uint32_t HW_HOP = 0x1EFFu;   // the hop and its flags
+__device__ __forceinline__ uint32_t hw_sig(uint32_t hw) { return (hw >> 13) & 127u; }
+__device__ __forceinline__ uint32_t hw_tr7(uint32_t hw) { return (hw >> 20) & 127u; }
+// the length of the point itself (a position inside a run holds a '00' point)
+__device__ __forceinline__ uint32_t hw_fixed(uint32_t hw) { return (hw & HW_RUN) ? 2u : (hw & 255u); }
+__device__ __forceinline__ uint32_t hw_zpc(uint32_t hw) { return (hw & HW_RUN) ? (hw & 255u) >> 1 : 0u; }
+
+// `at`: the position's place in its row of 64 (a run is cut where the row ends)
+template <int FMT>
+__device__ __forceinline__ uint32_t classify_position(uint64_t hi, uint32_t at)
+{
+    constexpr uint32_t HDR = (FMT == FMT_V2) ? 14u : 13u;
+    const uint32_t top = (uint32_t)(hi >> 32);
+    uint32_t ones = (uint32_t)__clz((int)~top);  // 32 when all ones
+    ones = ones > 4 ? 4u : ones;
+    constexpr uint32_t CLEN = 1u | (9u << 6) | (12u << 12) | (16u << 18) | (36u << 24);
+    const uint32_t clen = (CLEN >> (ones * 6u)) & 63u;
+    const bool eos = top == 0xFFFFFFFFu && (uint32_t)hi >= 0xF0000000u;  // '1111' and 32 ones
+    const uint32_t xh = (uint32_t)((hi << clen) >> 32);
+    const bool t2 = xh >= 0xC0000000u;
+    const bool t1 = !t2 && (int32_t)xh < 0;
+    uint32_t lead, sig;
+    if (FMT == FMT_V2) {
+        lead = (xh >> 24) & 63u;
+        sig = ((xh >> 18) & 63u) + 1u;
+    } else {
+        lead = (xh >> 25) & 31u;
+        sig = (xh >> 19) & 63u;
+        sig = sig ? sig : 64u;
+    }
+    const uint32_t trail = (64u - sig - lead) & 127u;
+    const uint32_t fixed = clen + (t2 ? HDR + sig : t1 ? 2u : 1u);
+    const uint32_t zbits = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
+    const uint32_t room = 64u - at;
+    const uint32_t zp = (zbits < room ? zbits : room) >> 1;
+    return (zp ? (2u * zp) | HW_RUN : fixed) | (t1 ? HW_T1 : 0u) | (t2 ? HW_T2 : 0u) | (eos ? HW_EOS : 0u) | (sig << 13) | (trail << 20);
+}
+
+struct WgLds {
+    uint64_t ring[RINGW];          // ring[w % RINGW] = image word w (zero beyond the image)
+    uint32_t hopw[2 * RPOS];       // hop word of bit position p at hopw[p % (2 RPOS)]
+    uint32_t queue[2][QCAP];       // queued starts of a region: position in the region | window << 16
+    uint64_t aggD[MAXB], aggS[MAXB], aggX[MAXB];  // per batch: sum of delta-of-deltas, sum of their running sums, XOR of the payloads
+    uint32_t qcount[2];
+    uint32_t kb[2];                // first batch that decoded a timestamp of zero (or none)
+    uint32_t anydd[2];             // some point of the region changed the interval
+    uint32_t stop, clean;          // the walker met the end of the stream or something for the serial decoder
+    uint32_t endrel, endwin;       // where the last queued point of the region ends, and the window after it
+    uint64_t sbits[RW];            // the walker's own: starts found by strides in the region under way (bit l of word r: position 64 r + l)
+};
+
+// A word of LDS that another wave wrote before the last barrier, as a scalar.
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+// All waves of the workgroup have carried out their LDS accesses up to here.  (Not __syncthreads(): that
+// would also wait for global memory, and the stores of decoded points are meant to stay in flight.)
+__device__ __forceinline__ void wg_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// -DGTSC_WG_STAMP: a diagnostic build that prints where the cycles of waves 0 and 1 of a block went (never shipped)
+#ifdef GTSC_WG_STAMP
+#define GTSC_WG_STAMP_DECL uint64_t tk_other = 0, tk_x1 = 0, tk_x2 = 0, tk_b1 = 0, tk_y = 0, tk_b2 = 0, tk_z = 0, tk_prev = __builtin_amdgcn_s_memtime(); uint32_t tk_ticks = 0;
+#define GTSC_WG_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
+#define GTSC_WG_STAMP_PRINT if (lane == 0 && wave < 2) printf("wave %u: x1 %llu x2 %llu b1 %llu y %llu b2 %llu z %llu other %llu\n", wave, (unsigned long long)tk_x1, (unsigned long long)tk_x2, (unsigned long long)tk_b1, (unsigned long long)tk_y, (unsigned long long)tk_b2, (unsigned long long)tk_z, (unsigned long long)tk_other);
+#else
+#define GTSC_WG_STAMP_DECL
+#define GTSC_WG_TICK(acc_)
+#define GTSC_WG_STAMP_PRINT
+#endif
+
+__device__ __forceinline__ int32_t sext7(uint32_t x) { return (int32_t)((x & 127u) ^ 64u) - 64; }
+
+// The walker's state: wave-uniform.
+struct Walk {
+    uint64_t cur;            // bit position where the next point starts
+    uint32_t wnb;            // value window in force: significant bits (0: none yet) ...
+    uint32_t wtr7;           // ... and trailing zeros, 7 bits
+    uint32_t last_len;       // length of the last point passed
+    bool last_t1;            // it reused the value window ('10')
+    uint32_t cool;           // rows to pass before strides are tried again
+    uint32_t found_total;    // points found so far, the block's first one included
+    bool stop, clean_end;
+};
+
+// Follows the chain of point starts through region k (positions [k RPOS, (k+1) RPOS)) from w.cur on and
+// queues them behind the qn points already there, looking at everything the reference's reads could meet:
+// the form for the ends of a block (its last regions, the points before the first value window, the last
+// points before the capacity is full).  Returns the number of points queued.
+__device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint32_t k, uint64_t limit, uint32_t cap, uint32_t lane, uint32_t qn)
+{
+    uint32_t* const q = L.queue[k & 1u];
+    const uint64_t g0 = (uint64_t)k * RPOS, rend = g0 + RPOS;
+    while (!w.stop && w.cur < rend) {
+        // ---- points of equal length: 64 candidate starts a stride apart, tested with one gathered read.
+        // The stride is the last point's length when that point reused the value window ('0'/'10'/'110'...,
+        // '10', payload): what a dense stream mostly consists of.
+        if (w.last_t1 && w.cool == 0 && w.wnb != 0) {
+            const uint32_t s = w.last_len;
+            const uint64_t cand = w.cur + (uint64_t)lane * s;
+            const bool inreg = cand < rend;
+            const uint32_t hw = inreg ? L.hopw[(uint32_t)cand & (2 * RPOS - 1)] : (HW_EOS | 0u);
+            const uint32_t len = hw_fixed(hw) + ((hw >> 10) & 1u) * w.wnb;
+            const bool ok = inreg && (hw & (HW_T2 | HW_EOS)) == 0 && len == s && cand + len < limit && w.found_total + lane < cap;
+            const uint64_t bad = lanes(!ok);
+            const uint32_t js = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+            if (js >= 4) {
+                if (lane < js) q[qn + lane] = (uint32_t)(cand - g0) | ((w.wnb | (w.wtr7 << 7)) << 16);
+                qn += js;
+                w.found_total += js;
+                w.cur += (uint64_t)js * s;
+                w.last_t1 = (read_lane(hw, js - 1) & HW_T1) != 0;
+                continue;
+            }
+            // the chain broke right away (not merely at the region's end): hops for a while
+            if (read_lane((uint32_t)inreg, js)) w.cool = 8;
+        }
+        // ---- one row of 64 positions: lane l looks at position row + l
+        const uint64_t row = w.cur & ~63ull;
+        uint32_t p = (uint32_t)w.cur & 63u;
+        const uint32_t hw = L.hopw[((uint32_t)row & (2 * RPOS - 1)) + lane];
+        const uint32_t t1 = (hw >> 10) & 1u;
+        uint32_t len = hw_fixed(hw) + t1 * w.wnb;
+        const uint32_t zpc = hw_zpc(hw);                  // '00' points from here on, inside the row
+        const uint32_t sig = hw_sig(hw), tr7 = hw_tr7(hw);
+        uint32_t lane_win = w.wnb | (w.wtr7 << 7);        // the window in force at this lane's position
+        uint64_t real = 0;
+        uint32_t found = 0;
+        // Far from the end of the image and of the capacity, with a window defined and no end marker in the
+        // row, a hop has nothing to check.
+        const bool safe = w.wnb != 0 && !any_lane((hw & HW_EOS) != 0) && row + 64 + 128 < limit && w.found_total + 64 < cap;
+        if (safe) {
+            // every position knows its own hop -- a run of unchanged points or its length -- and the starts it
+            // stands for, so that a hop of the scalar chain is three lane reads, an OR and an add
+            const uint64_t own = zpc ? (0x5555555555555555ull >> (64u - 2u * zpc)) << lane : 1ull << lane;
+            const uint32_t flags = hw & (HW_T1 | HW_T2);   // 0x400: '10', 0x800: '11'
+            uint32_t hop = zpc ? (2u * zpc) | 0x200u : len | flags;
+            uint32_t kk = 0;
+            while (p < 64) {
+                kk = read_lane(hop, p);
+                real |= read_lane(own, p);
+                if (kk & 0x800u) {
+                    // a new window from here on: positions that reuse the window change length
+                    w.wnb = read_lane(sig, p);
+                    w.wtr7 = read_lane(tr7, p);
+                    len = hw_fixed(hw) + t1 * w.wnb;
+                    hop = zpc ? hop : len | flags;
+                    if (lane > p) lane_win = w.wnb | (w.wtr7 << 7);
+                }
+                p += kk & 255u;
+            }
+            found = (uint32_t)__builtin_popcountll(real);
+            w.last_len = (kk & 0x200u) ? 2u : (kk & 255u);
+            w.last_t1 = (kk & 0x400u) != 0;
+        } else {
+            // near an end, or before the first window: every hop looks at what the reference's reads would meet
+            uint32_t packed = len | (hw & (HW_T1 | HW_T2 | HW_EOS)) >> 2;   // 0x100: '10', 0x200: '11', 0x400: end marker
+            while (p < 64) {
+                const uint64_t here = row + p;
+                uint32_t zz = read_lane(zpc, p);
+                if (zz) {
+                    bool cut = false;
+                    const uint64_t room = limit > here ? (limit - here - 1) >> 1 : 0;   // points of 2 bits that end before the limit
+                    const uint32_t left = cap - w.found_total - found;                  // and fit the capacity
+                    if (zz > room) { zz = (uint32_t)room; cut = true; }
+                    if (zz > left) { zz = left; cut = true; }
+                    if (zz) {
+                        real |= (0x5555555555555555ull >> (64u - 2u * zz)) << p;
+                        found += zz;
+                        p += 2u * zz;
+                        w.last_len = 2;
+                        w.last_t1 = false;
+                    }
+                    if (cut) { w.stop = true; break; }
+                    continue;
+                }
+                const uint32_t pk = read_lane(packed, p);
+                const uint32_t l = pk & 255u;
+                if (pk & 0x400u) {
+                    w.stop = true;
+                    w.clean_end = here + 36 < limit;   // the marker itself must not run off the image
+                    break;
+                }
+                if (((pk & 0x100u) && w.wnb == 0) || here + l >= limit || w.found_total + found >= cap) { w.stop = true; break; }
+                real |= 1ull << p;
+                found++;
+                if (pk & 0x200u) {
+                    w.wnb = read_lane(sig, p);
+                    w.wtr7 = read_lane(tr7, p);
+                    len = hw_fixed(hw) + t1 * w.wnb;
+                    packed = len | (hw & (HW_T1 | HW_T2 | HW_EOS)) >> 2;
+                    if (lane > p) lane_win = w.wnb | (w.wtr7 << 7);
+                }
+                p += l;
+                w.last_len = l;
+                w.last_t1 = (pk & 0x100u) != 0;
+            }
+        }
+        // queue the real starts
+        if ((real >> lane) & 1u) {
+            const uint32_t at = qn + (uint32_t)__builtin_popcountll(real & ((1ull << lane) - 1ull));
+            q[at] = ((uint32_t)(row - g0) + lane) | (lane_win << 16);
+        }
+        qn += found;
+        w.found_total += found;
+        w.cur = row + p;
+        w.cool -= w.cool ? 1u : 0u;
+    }
+    return qn;
+}
+
+// The same for a region that lies well inside the image (no field of a point that starts in it can run off the
+// image), once a value window exists: nothing to check but the end marker and the capacity.  The walker visits
+// the region's rows of 64 positions in turn.  Lane l of the row's hop words is read with a scalar index, the
+// row's starts collect in a scalar mask, and lane r of two registers keeps the mask of row r; the chain of hops
+// itself is eight scalar instructions per hop (hop_chain()).  The queue is written once per region, lane r handing
+// over the starts of row r in order with the window in force at each (a '11' point changes it for the points
+// after it).
+// Returns the number of points queued; `handover`: the walk stopped before the region's end (w.cur says where)
+// and walk_region_careful() has the rest.
+
+// The chain of hops through the rows of a region, as one piece of assembly: the compiler's own code for such a
+// loop costs ten taken branches a row, and a lone wave pays a refill of its instruction buffer for each.  This
+// form has one taken branch per row and one per hop after a row's first.
+//
+// State: row r (< 64) and position q in it; `real`: the starts found in the row so far; lane l of `hop` holds the
+// hop from position l of the row in its low byte and flags above (a run of '00' points, a '11' code, an end
+// marker); lane r of blo/bhi receives the finished mask of row r and lane r of rowwin the window in force where
+// the row begins; `found` counts the starts.  base: LDS byte address of this lane's hop word in row 0.
+// mode 0 starts at (r, q) with a fresh row; mode 1 resumes inside the row (hw/hop/real as left, hop recomputed by
+// the caller after a window change).
+// Returns 0 with r >= stoprow (the region's end, or where the caller wants a word) or found >= budget (the capacity
+// may fill up inside the next row), the row's mask stored; 2 before a hop that is a '11' code or an end marker
+// (kk holds its hop word, r/q/real say where): the caller's business.
+__device__ __forceinline__ uint32_t walk_rows(uint32_t mode, uint32_t& r, uint32_t& q, uint64_t& real, uint32_t& kk,
+                                              uint32_t& found, uint32_t budget, uint32_t stoprow, uint32_t win,
+                                              uint32_t& hw, uint32_t& hwn, uint32_t& hop, uint32_t& va, uint32_t& blo,
+                                              uint32_t& bhi, uint32_t& rowwin, uint32_t base)
+{
+    uint32_t code, t, vt;
+    uint32_t rlo = (uint32_t)real, rhi = (uint32_t)(real >> 32);
+    const uint32_t wnb = win & 127u;
+    const uint64_t c5 = 0x5555555555555555ull;
+    asm volatile(
+        "s_mov_b32 s96, %[rlo]\n\t"
+        "s_mov_b32 s97, %[rhi]\n\t"
+        "s_cmp_eq_u32 %[mode], 0\n\t"
+        "s_cbranch_scc0 4f\n\t"
+        // ---- a fresh row: its hop words and those of the row after it
+        "v_lshl_add_u32 %[va], %[r], 8, %[base]\n\t"
+        "ds_read_b32 %[hw], %[va]\n\t"
+        "v_add_u32 %[va], 0x100, %[va]\n\t"
+        "ds_read_b32 %[hwn], %[va]\n\t"
+        "s_waitcnt lgkmcnt(1)\n"
+        "1:\n\t"
+        "s_mov_b32 m0, %[r]\n\t"
+        "v_bfe_u32 %[vt], %[hw], 10, 1\n\t"
+        "v_and_b32 %[hop], 0x1eff, %[hw]\n\t"
+        "v_writelane_b32 %[rowwin], %[win], m0\n\t"
+        "v_mad_u32_u24 %[hop], %[vt], %[wnb], %[hop]\n\t"
+        "s_nop 1\n"
+        "2:\n\t"
+        "v_readlane_b32 %[kk], %[hop], %[q]\n\t"
+        "s_and_b32 %[t], %[kk], 0x1a00\n\t"
+        "s_cbranch_scc1 6f\n\t"
+        "s_bitset1_b64 s[96:97], %[q]\n"
+        "3:\n\t"
+        "s_and_b32 %[t], %[kk], 0xff\n\t"
+        "s_add_u32 %[q], %[q], %[t]\n"
+        "4:\n\t"
+        "s_cmp_lt_u32 %[q], 64\n\t"
+        "s_cbranch_scc1 2b\n\t"
+        // ---- the row is done
+        "s_mov_b32 m0, %[r]\n\t"
+        "s_bcnt1_i32_b64 %[t], s[96:97]\n\t"
+        "s_add_u32 %[found], %[found], %[t]\n\t"
+        "v_writelane_b32 %[blo], s96, m0\n\t"
+        "v_writelane_b32 %[bhi], s97, m0\n\t"
+        "s_mov_b64 s[96:97], 0\n\t"
+        "s_lshr_b32 %[t], %[q], 6\n\t"
+        "s_add_u32 %[r], %[r], %[t]\n\t"
+        "s_and_b32 %[q], %[q], 63\n\t"
+        "s_cmp_ge_u32 %[r], %[stoprow]\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "s_cmp_ge_u32 %[found], %[budget]\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "s_cmp_eq_u32 %[t], 1\n\t"
+        "s_cbranch_scc0 5f\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mov_b32 %[hw], %[hwn]\n\t"
+        "v_add_u32 %[va], 0x100, %[va]\n\t"
+        "ds_read_b32 %[hwn], %[va]\n\t"
+        "s_branch 1b\n"
+        "5:\n\t"   // the chain hopped over a whole row
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshl_add_u32 %[va], %[r], 8, %[base]\n\t"
+        "ds_read_b32 %[hw], %[va]\n\t"
+        "v_add_u32 %[va], 0x100, %[va]\n\t"
+        "ds_read_b32 %[hwn], %[va]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "s_branch 1b\n"
+        "6:\n\t"   // not a plain point
+        "s_bitcmp1_b32 %[kk], 9\n\t"
+        "s_cbranch_scc0 7f\n\t"
+        "s_and_b32 %[t], %[kk], 0xff\n\t"   // a run of '00' points: bits q, q + 2, ...
+        "s_sub_u32 %[t], 64, %[t]\n\t"
+        "s_lshr_b64 s[98:99], %[c5], %[t]\n\t"
+        "s_lshl_b64 s[98:99], s[98:99], %[q]\n\t"
+        "s_or_b64 s[96:97], s[96:97], s[98:99]\n\t"
+        "s_branch 3b\n"
+        "7:\n\t"
+        "s_mov_b32 %[code], 2\n\t"
+        "s_branch 9f\n"
+        "8:\n\t"
+        "s_mov_b32 %[code], 0\n"
+        "9:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %[rlo], s96\n\t"
+        "s_mov_b32 %[rhi], s97\n"
+        : [code] "=&s"(code), [t] "=&s"(t), [vt] "=&v"(vt), [kk] "+s"(kk), [r] "+s"(r), [q] "+s"(q), [found] "+s"(found),
+          [rlo] "+s"(rlo), [rhi] "+s"(rhi), [hw] "+v"(hw), [hwn] "+v"(hwn), [hop] "+v"(hop), [va] "+v"(va), [blo] "+v"(blo),
+          [bhi] "+v"(bhi), [rowwin] "+v"(rowwin)
+        : [mode] "s"(mode), [budget] "s"(budget), [stoprow] "s"(stoprow), [win] "s"(win), [wnb] "s"(wnb), [c5] "s"(c5), [base] "v"(base)
+        : "scc", "m0", "s96", "s97", "s98", "s99", "memory");
+    real = ((uint64_t)rhi << 32) | rlo;
+    return code;
+}
+
+// The same for a region that lies well inside the image (no field of a point that starts in it can run off the
+// image), once a value window exists: nothing to check but the end marker and the capacity.  walk_rows() follows
+// the hops; what it leaves to this function are window changes, and strides: where the last point reused the
+// window, 64 candidate starts that point's length apart are tested with one gathered read -- a stream of
+// equal-sized points is taken 64 points at a time.  The queue is written once per region, lane r handing over
+// the starts of row r in order with the window in force at each (a '11' point changes it for the points after it).
+// Returns the number of points queued; `handover`: the walk stopped before the region's end (w.cur says where)
+// and walk_region_careful() has the rest.
+__device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t k, uint32_t cap, uint32_t lane, bool& handover)
+{
+    uint32_t* const qd = L.queue[k & 1u];
+    const uint32_t* const hrow = L.hopw + (k & 1u) * RPOS + lane;
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)hrow;
+    uint32_t p = (uint32_t)w.cur & (RPOS - 1);     // position inside the region
+    uint32_t win = w.wnb | (w.wtr7 << 7);          // the value window in force: significant bits | trailing zeros << 7
+    uint32_t kk = w.last_t1 ? (w.last_len | HW_T1) : w.last_len;   // the last hop
+    uint32_t found = 0;
+    // points the region may still take before the capacity could fill up inside a row (a row holds 32 at most)
+    const uint32_t left = cap - w.found_total;     // (> 0: the careful walk stops at the capacity)
+    const uint32_t budget = left > 32 ? left - 32 : 0u;
+    uint32_t blo = 0, bhi = 0, rowwin = 0;         // lane r: the starts of row r, the window in force where the row begins
+    uint32_t next_try = (p >> 6) + w.cool;         // the row from which strides are tried again
+    uint32_t backoff = 8;
+    bool strided = false;
+    uint32_t lastgen = ~0u;                        // the last row the chain went through hop by hop
+    handover = false;
+    uint32_t r = p >> 6, q = p & 63u;
+    uint32_t hw = 0, hwn = 0, hop = 0, va = 0;
+    uint64_t real = 0;
+    uint32_t mode = 0;
+    while (r < RW) {
+        if (mode == 0) {
+            if (found >= budget) { handover = true; break; }
+            // ---- points of equal length: 64 candidate starts a stride apart
+            if ((kk & HW_T1) && !(kk & HW_RUN) && r >= next_try) {
+                const uint32_t s = kk & 255u;
+                const uint32_t cand = r * 64 + q + lane * s;
+                const bool inreg = cand < RPOS;
+                const uint32_t hc = inreg ? hrow[(int32_t)cand - (int32_t)lane] : HW_EOS;
+                const uint32_t lc = hw_fixed(hc) + ((hc >> 10) & 1u) * (win & 127u);
+                const bool ok = (hc & (HW_T2 | HW_EOS)) == 0 && lc == s && found + lane < left;
+                const uint64_t bad = lanes(!ok);
+                const uint32_t js = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                if (js >= 4) {
+                    if (lane < js) atomicOr(reinterpret_cast<unsigned long long*>(&L.sbits[cand >> 6]), 1ull << (cand & 63u));
+                    // (rows the stride passes through get the window in force: it does not change on the way; row r
+                    // has its own from the hops that came through it, if any did)
+                    if (lane > r || (lane == r && lastgen != r)) rowwin = win;
+                    strided = true;
+                    found += js;
+                    const uint32_t pn = r * 64 + q + js * s;
+                    r = pn >> 6; q = pn & 63u;
+                    kk = (read_lane(hc, js - 1) & HW_T1) ? (s | HW_T1) : s;
+                    backoff = 8;
+                    continue;
+                }
+                // the chain broke right away (not merely at the region's end): hops for a while
+                if (read_lane((uint32_t)inreg, js)) { next_try = r + backoff; backoff = backoff < 64 ? backoff * 2 : 64u; }
+            }
+        }
+        // ---- hops: to the region's end, or to the row where a stride may be tried again
+        const uint32_t stoprow = next_try > r && next_try < RW ? next_try : RW;
+        lastgen = r;   // (and the rows after it: a stride only ever starts where the hops stopped)
+        const uint32_t code = walk_rows(mode, r, q, real, kk, found, budget, stoprow, win, hw, hwn, hop, va, blo, bhi, rowwin, base);
+        mode = 0;
+        if (code == 2) {
+            if (kk & HW_T2) {
+                // a new window from here on: positions that reuse the window change length
+                win = (read_lane(hw, q) >> 13) & 0x3FFFu;
+                hop = (hw & HW_HOP) + ((hw >> 10) & 1u) * (win & 127u);
+                real |= 1ull << q;
+                q += kk & 255u;
+                mode = 1;
+                lastgen = r;
+            } else {
+                // what looks like the end marker: the careful walk has it (the starts of the row so far go along)
+                blo = write_lane(blo, (uint32_t)real, r);
+                bhi = write_lane(bhi, (uint32_t)(real >> 32), r);
+                found += (uint32_t)__builtin_popcountll(real);
+                handover = true;
+                break;
+            }
+        } else {
+            lastgen = r - 1;
+            if (found >= budget && r < RW) { handover = true; break; }
+        }
+    }
+    p = r * 64 + q;
+    // ---- the queue: lane r hands over the starts of row r
+    uint64_t wb = ((uint64_t)bhi << 32) | blo;
+    if (strided) { wave_sync(); wb |= L.sbits[lane]; L.sbits[lane] = 0; }
+    const uint32_t c = (uint32_t)__builtin_popcountll(wb);
+    const uint32_t incl = wave_inclusive_sum(c);
+    uint32_t at = incl - c;
+    uint32_t cw = rowwin;
+    while (any_lane(wb != 0)) {
+        if (wb) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(wb);
+            wb &= wb - 1;
+            const uint32_t h = hrow[(int32_t)(lane * 64 + t) - (int32_t)lane];
+            qd[at++] = (lane * 64 + t) | (cw << 16);
+            if (h & HW_T2) cw = (h >> 13) & 0x3FFFu;
+        }
+    }
+    w.cur = (w.cur & ~(uint64_t)(RPOS - 1)) + p;
+    w.wnb = win & 127u; w.wtr7 = win >> 7;
+    w.last_len = (kk & HW_RUN) ? 2u : (kk & 255u);
+    w.last_t1 = (kk & HW_T1) != 0 && !(kk & HW_RUN);
+    w.cool = next_try > r && r < RW ? next_try - r : 0u;
+    w.found_total += found;
+    return read_lane(incl, 63);
+}
+
+// Decompresses block `s` with the whole workgroup of NW waves.
+template <int FMT, uint32_t NW>
+__device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s, WgLds& L, uint32_t tid)
+{
+    constexpr uint32_t NT = NW * 64, NH = NW - 1;           // threads; helper waves
+    constexpr uint32_t MB = (MAXB + NH - 1) / NH;           // batches a helper wave may have to emit per region
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint64_t ssz64 = a.slots.size(s);
+    const uint64_t* const image = a.words + a.slots.begin(s);
+    uint64_t nw64 = a.in_nwords ? a.in_nwords[s] : ssz64;
+    if (nw64 > ssz64) nw64 = ssz64;                     // an image cannot be longer than its slot
+    const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
+    const uint64_t p0 = a.pts.begin(s);
+    const uint64_t cap64 = a.pts.size(s);
+    const uint32_t cap = cap64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)cap64;   // as in the lane-per-series kernels
+    const uint64_t limit = (uint64_t)nw * 64;           // a field must end before this bit (G/LongArrayInput.java:48-52)
+
+    // ---- state at the last point handed to the output ("committed"): where the serial decoder takes over.
+    // Every wave keeps its own copy and moves it on in the same way.
+    uint64_t pos = 0;                 // bit position of the next unread bit
+    uint32_t n = 0;                   // points decoded
+    uint64_t stored_delta = 0, stored_ts = 0, val = 0;
+    uint32_t win = 0;                 // value window: significant bits (0: none yet) | trailing zeros (7 bits) << 7
+    bool serial = nw < 4;             // tiny images: the serial decoder from the start
+    bool finished = false;
+
+    if (!serial) {
+        // header and first point (G/GorillaDecompressor.java:27-35,62-72): nw >= 4, so neither runs off the image
+        const uint64_t w0 = image[0], w1 = image[1], w2 = image[2];
+        const uint32_t d = (uint32_t)(w1 >> 37);
+        if (d == 0x7FFFFFFu) {
+            finished = true;                             // empty block
+        } else {
+            val = (w1 << 27) | (w2 >> 37);
+            stored_delta = d;
+            stored_ts = w0 + d;
+            pos = 64 + 91;
+            n = 1;
+            if (cap == 0 || stored_ts == 0) { serial = true; pos = 64; n = 0; stored_ts = 0; stored_delta = 0; val = 0; }
+            else if (tid == 0) { a.ts[p0] = (int64_t)stored_ts; a.val[p0] = val; }
+        }
+    }
+    bool clean_end = finished;
+
+    if (!finished && !serial) {
+        auto word = [&](uint32_t w) -> uint64_t { return w < nw ? image[w] : 0ull; };
+        // ---- prologue: image words [0, 2 RW], the hop words of region 0
+        for (uint32_t w = tid; w < 2 * RW + 1; w += NT) L.ring[w] = word(w);
+        if (tid == 0) { L.stop = 0; L.clean = 0; L.qcount[0] = 0; L.qcount[1] = 0; }
+        if (tid < RW) L.sbits[tid] = 0;
+        wg_barrier();
+        auto classify_region = [&](uint32_t r, uint32_t first_task, uint32_t tasks_step) {
+            // four consecutive positions per task: they share the two image words they look at
+            const uint64_t g = (uint64_t)r * RPOS;
+            for (uint32_t t = first_task; t < RPOS / 4; t += tasks_step) {
+                const uint64_t P = g + 4u * t;
+                const uint32_t kw = (uint32_t)(P >> 6), o = (uint32_t)P & 63u;
+                const uint64_t r0 = L.ring[kw & (RINGW - 1)], r1 = L.ring[(kw + 1) & (RINGW - 1)];
+                uint4 h;
+                h.x = classify_position<FMT>(WindowDecoder<FMT>::window(r0, r1, o), o);
+                h.y = classify_position<FMT>(WindowDecoder<FMT>::window(r0, r1, o + 1), o + 1);
+                h.z = classify_position<FMT>(WindowDecoder<FMT>::window(r0, r1, o + 2), o + 2);
+                h.w = classify_position<FMT>(WindowDecoder<FMT>::window(r0, r1, o + 3), o + 3);
+                *reinterpret_cast<uint4*>(&L.hopw[((uint32_t)P & (2 * RPOS - 1))]) = h;
+            }
+        };
+        classify_region(0, tid, NT);
+        wg_barrier();
+
+        Walk wk{pos, 0u, 0u, 0u, false, 0u, 1u, false, false};
+        GTSC_WG_STAMP_DECL
+        bool stop_prev = false;       // the walker stopped in the tick before: this one only emits
+        uint32_t qprev = 0;           // points the walker queued in the tick before
+        for (uint32_t k = 0;; k++) {
+            const uint32_t slot = k & 1u, pslot = slot ^ 1u;
+            uint64_t s_loc[MB], x_loc[MB];
+            // ---- the walker in region k; the others classify region k + 1 and parse what was queued in region k - 1
+            GTSC_WG_TICK(tk_other)
+            if (wave == 0) {
+                uint32_t qn = 0;
+                if (!stop_prev) {
+                    bool rest = true;
+                    if (wk.wnb != 0 && (uint64_t)(k + 1) * RPOS + 256 < limit) qn = walk_region_fast(wk, L, k, cap, lane, rest);
+                    if (rest) qn = walk_region_careful(wk, L, k, limit, cap, lane, qn);
+                }
+                if (lane == 0) {
+                    L.qcount[slot] = qn;
+                    L.stop = wk.stop ? 1u : 0u;
+                    L.clean = wk.clean_end ? 1u : 0u;
+                    L.kb[slot] = 0xFFFFFFFFu;   // (for the tick after this one)
+                    L.anydd[slot] = 0;
+                }
+            } else {
+                uint64_t landing = 0;
+                const uint32_t lw = (k + 2) * RW + 1 + lane;   // words [(k+2) RW + 1, (k+3) RW]: what region k + 2's positions look at
+                if (!stop_prev) {
+                    if (wave == 1) landing = word(lw);
+                    classify_region(k + 1, (wave - 1) * 64 + lane, NH * 64);
+                }
+                GTSC_WG_TICK(tk_x1)
+#pragma unroll
+                for (uint32_t j = 0; j < MB; j++) {
+                    const uint32_t b = (wave - 1) + j * NH;
+                    s_loc[j] = 0; x_loc[j] = 0;
+                    if (b * 64 < qprev) {
+                        const uint32_t m = qprev - b * 64 < 64 ? qprev - b * 64 : 64u;
+                        const bool have = lane < m;
+                        const uint32_t e = have ? L.queue[pslot][b * 64 + lane] : 0u;
+                        const uint32_t rel = e & 0xFFFFu;
+                        const uint64_t bp = (uint64_t)(k - 1) * RPOS + rel;
+                        const uint32_t kw = (uint32_t)(bp >> 6), o = (uint32_t)bp & 63u;
+                        const uint64_t r0 = L.ring[kw & (RINGW - 1)], r1 = L.ring[(kw + 1) & (RINGW - 1)],
+                                       r2 = L.ring[(kw + 2) & (RINGW - 1)];
+                        WindowDecoder<FMT> d;
+                        d.off = 0; d.widx = 0; d.nwords = 0xFFFFFFFFu;
+                        d.nbits = (e >> 16) & 127u;
+                        d.trail = sext7(e >> 23);
+                        const uint64_t hi = WindowDecoder<FMT>::window(r0, r1, o), lo = WindowDecoder<FMT>::window(r1, r2, o);
+                        const typename WindowDecoder<FMT>::Parsed pq = d.template parse<false>(hi, [lo] { return lo; });
+                        const uint64_t x = have ? pq.bits << ((uint32_t)pq.trail & 63u) : 0ull;
+                        const uint64_t dd = have ? (uint64_t)pq.dd : 0ull;
+                        uint64_t dsum = 0, ssum = 0;
+                        if (any_lane(dd != 0)) {
+                            dsum = wave_inclusive_scan64<false>(dd);
+                            ssum = wave_inclusive_scan64<false>(dsum);
+                            if (lane == 0) L.anydd[pslot] = 1u;
+                        }
+                        const uint64_t xsum = wave_inclusive_scan64<true>(x);
+                        s_loc[j] = ssum; x_loc[j] = xsum;
+                        if (lane == m - 1) {
+                            L.aggD[b] = dsum; L.aggS[b] = ssum; L.aggX[b] = xsum;
+                            if (b * 64 + m == qprev) {   // the region's last point: where it ends, and the window after it
+                                L.endrel = rel + pq.o3;
+                                L.endwin = pq.nbits | (((uint32_t)pq.trail & 127u) << 7);
+                            }
+                        }
+                    }
+                }
+                if (!stop_prev && wave == 1) L.ring[lw & (RINGW - 1)] = landing;
+            }
+            GTSC_WG_TICK(tk_x2)
+            wg_barrier();
+            GTSC_WG_TICK(tk_b1)
+            const uint32_t qnow = lds_peek(&L.qcount[slot]);
+            const bool stop_now = lds_peek(&L.stop) != 0;
+            if (stop_now) clean_end = lds_peek(&L.clean) != 0;
+            uint32_t kbv = 0xFFFFFFFFu;
+            const uint32_t nb = (qprev + 63) / 64;
+            if (qprev) {
+                // ---- from the batches' sums to the state before each batch (every wave works this out for itself):
+                // deltas are the running sum of the delta-of-deltas, timestamps of the deltas
+                const bool mineb = lane < nb;
+                const uint64_t cnt = mineb ? (qprev - lane * 64 < 64 ? qprev - lane * 64 : 64u) : 0u;
+                uint64_t delta_in = stored_delta, ts_in, dinc = 0, tinc;
+                if (lds_peek(&L.anydd[pslot])) {
+                    const uint64_t D = mineb ? L.aggD[lane] : 0ull, S = mineb ? L.aggS[lane] : 0ull;
+                    dinc = wave_inclusive_scan64<false>(D);
+                    delta_in = stored_delta + dinc - D;
+                    const uint64_t T = cnt * delta_in + S;
+                    tinc = wave_inclusive_scan64<false>(T);
+                    ts_in = stored_ts + tinc - T;
+                } else {
+                    // regular cadence throughout: no sums needed
+                    tinc = (uint64_t)(lane * 64u + (uint32_t)cnt) * stored_delta;
+                    ts_in = stored_ts + (uint64_t)(lane * 64u) * stored_delta;
+                }
+                const uint64_t X = mineb ? L.aggX[lane] : 0ull;
+                const uint64_t xinc = wave_inclusive_scan64<true>(X);
+                const uint64_t val_in = val ^ xinc ^ X;
+                // ---- the helpers' points
+                uint64_t ts_out[MB], v_out[MB];
+                if (wave != 0) {
+#pragma unroll
+                    for (uint32_t j = 0; j < MB; j++) {
+                        const uint32_t b = (wave - 1) + j * NH;
+                        ts_out[j] = 1; v_out[j] = 0;
+                        if (b * 64 < qprev) {
+                            const uint32_t m = qprev - b * 64 < 64 ? qprev - b * 64 : 64u;
+                            const uint64_t db = read_lane(delta_in, b), tb = read_lane(ts_in, b), vb = read_lane(val_in, b);
+                            ts_out[j] = tb + (uint64_t)(lane + 1) * db + s_loc[j];
+                            v_out[j] = vb ^ x_loc[j];
+                            // a timestamp of exactly zero turns the next point into a "first" one: not this path's business
+                            if (any_lane(lane < m && ts_out[j] == 0) && lane == 0) atomicMin(&L.kb[pslot], b);
+                        }
+                    }
+                }
+                GTSC_WG_TICK(tk_y)
+                wg_barrier();
+                GTSC_WG_TICK(tk_b2)
+                kbv = lds_peek(&L.kb[pslot]);
+                if (wave != 0) {
+#pragma unroll
+                    for (uint32_t j = 0; j < MB; j++) {
+                        const uint32_t b = (wave - 1) + j * NH;
+                        if (b * 64 < qprev && b < kbv) {
+                            const uint32_t m = qprev - b * 64 < 64 ? qprev - b * 64 : 64u;
+                            if (lane < m) {
+                                __builtin_nontemporal_store((int64_t)ts_out[j], a.ts + p0 + n + b * 64 + lane);
+                                __builtin_nontemporal_store(v_out[j], a.val + p0 + n + b * 64 + lane);
+                            }
+                        }
+                    }
+                }
+                // ---- commit
+                const uint64_t g = (uint64_t)(k - 1) * RPOS;
+                if (kbv >= nb) {
+                    stored_delta = stored_delta + read_lane(dinc, nb - 1);
+                    stored_ts = stored_ts + read_lane(tinc, nb - 1);
+                    val = val ^ read_lane(xinc, nb - 1);
+                    n += qprev;
+                    pos = g + lds_peek(&L.endrel);
+                    win = lds_peek(&L.endwin);
+                } else {
+                    // up to the batch that met a zero timestamp; the serial decoder has the rest
+                    stored_delta = read_lane(delta_in, kbv);
+                    stored_ts = read_lane(ts_in, kbv);
+                    val = read_lane(val_in, kbv);
+                    n += kbv * 64;
+                    const uint32_t e = lds_peek(&L.queue[pslot][kbv * 64]);
+                    pos = g + (e & 0xFFFFu);
+                    win = e >> 16;
+                    serial = true;
+                }
+            }
+            GTSC_WG_TICK(tk_z)
+            if (serial || stop_prev) break;
+            stop_prev = stop_now;
+            qprev = qnow;
+        }
+        GTSC_WG_STAMP_PRINT
+    }
+    uint32_t st = 0;
+    if (!clean_end || serial) {
+        // ---- the serial decoder, one lane, from the committed state (exact order of the reference's checks)
+        if (tid == 0) {
+            auto src = [&](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
+            Decoder<FMT> d;
+            if (nw < 4 || pos < 64) {
+                d.begin(nw, src);
+            } else {
+                const uint32_t nbits = win & 127u;
+                const int32_t trail = sext7(win >> 7);
+                d.nwords = nw;
+                d.widx = (uint32_t)(pos >> 6); d.off = (uint32_t)pos & 63u;
+                d.r0 = src(d.widx); d.r1 = src(d.widx + 1); d.r2 = src(d.widx + 2); d.r3 = src(d.widx + 3);
+                d.st = 0;
+                d.block_ts = (int64_t)src(0); d.stored_delta = (int64_t)stored_delta; d.stored_ts = stored_ts; d.val = val; d.pred_last = 0;
+                d.lead = nbits ? (uint32_t)(64 - (int32_t)nbits - trail) : NO_WINDOW;
+                d.trail = trail;
+            }
+            int64_t t; uint64_t v;
+            while (d.next(t, v, src)) {
+                if (n < cap) { a.ts[p0 + n] = t; a.val[p0 + n] = v; } else st = ST_OVERFLOW;
+                n++;
+            }
+            st |= d.st;
+        }
+    }
+    if (tid == 0) {
+        a.out_npoints[s] = n;
+        if (a.status) a.status[s] = st;
+        if (st) atomicOr(a.flags, st);
+    }
+}
+
+template <int FMT, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void decode_block_wg_kernel(DecodeArgs a, uint32_t per_group)
+{
+    __shared__ WgLds L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint64_t cand = blockIdx.x + (uint64_t)lane * gridDim.x;
+    const bool mine = lane < per_group && cand < a.nseries && block_owner(a, cand) == OWNER_WG;
+    uint64_t todo = lanes(mine);   // (the same in every wave)
+    while (todo) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        decode_block_wg<FMT, NW>(a, blockIdx.x + (uint64_t)j * gridDim.x, L, tid);
+        __syncthreads();   // the next block starts over in LDS
+    }
+}
+
+}  // namespace
+
+hipError_t launch_decode_blocks_wg(const DecodeArgs& a, int format, hipStream_t stream)
+{
+    if (a.nseries == 0) return hipSuccess;
+    if (a.dispatch) *a.dispatch |= DISPATCH_WG;
+    uint64_t per_group = a.nseries / 16384;
+    per_group = per_group < 1 ? 1 : per_group > 64 ? 64 : per_group;
+    const uint32_t grid = (uint32_t)((a.nseries + per_group - 1) / per_group);
+    if (format == FMT_V2) hipLaunchKernelGGL((decode_block_wg_kernel<FMT_V2, 16>), dim3(grid), dim3(64 * 16), 0, stream, a, (uint32_t)per_group);
+    else                  hipLaunchKernelGGL((decode_block_wg_kernel<FMT_V1, 16>), dim3(grid), dim3(64 * 16), 0, stream, a, (uint32_t)per_group);
+    return hipGetLastError();
+}
+
+}  // namespace gtsc

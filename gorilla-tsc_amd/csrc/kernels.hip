@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
     if (st) atomicOr(a.flags, st);
 }
 
-// true when series s is the wave-per-block decoder's: long, and the batch holds few enough long ones
+// true when series s is a wave's or a workgroup's: long, and the batch holds few enough long ones
 __device__ __forceinline__ bool left_to_block_kernel(const DecodeArgs& a, uint64_t s)
 {
-    return a.pts.size(s) >= a.long_threshold && (!a.long_count || *a.long_count <= a.long_max_series);
+    return block_owner(a, s) != OWNER_LANE;
 }
 
 template <int FMT, int PRED = PRED_LAST>
@@ -671,20 +671,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
     }
-    // How dense the streams are (words written, points coded): one wave in 64 reports, the library chooses
-    // the kernel for long blocks of the batches that follow from the ratio.
-    if (a.stats && (blockIdx.x & 63u) == 0) {
-        uint32_t words = valid ? e.widx : 0u, points = np;
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) {
-            words += (uint32_t)__shfl_xor((int)words, k, 64);
-            points += (uint32_t)__shfl_xor((int)points, k, 64);
-        }
-        if (lane == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, (unsigned long long)words);
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 4, (unsigned long long)points);
-        }
-    }
 }
 
 // Decoder geometry.  Output tiles hold 16 slots per row like the encoder's: stores of whole
@@ -752,6 +738,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint64_t tk_p1 = 0, tk_p2 = 0;
 #endif
     const uint32_t lane = threadIdx.x;
+    if (a.ring_by_plan) {
+        // both forms of the kernel were launched: the one that suits the batch's density works (above 40 compressed bits
+        // per point of capacity the 16-word rings)
+        const bool dense = a.plan->words_all * 64 > a.plan->cap_all * 40;
+        if (dense != (RING == 16)) return;
+    }
     const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
     const bool valid = s < a.nseries && !left_to_block_kernel(a, s);
 #ifdef GTSC_STAMP
@@ -1361,20 +1353,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
     }
-    // What the wave read and produced: the library chooses the ring from the ratio.  One wave in 64
-    // reports (a sample is enough, and 30,000 atomics on one address would take as long as a tenth of the kernel).
-    if (a.stats && (blockIdx.x & 63u) == 0) {
-        uint32_t words = valid ? (d.widx < nw ? d.widx : nw) : 0u, points = valid ? (n < cap ? n : cap) : 0u;
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) {
-            words += (uint32_t)__shfl_xor((int)words, k, 64);
-            points += (uint32_t)__shfl_xor((int)points, k, 64);
-        }
-        if (lane == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats), (unsigned long long)words);
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 1, (unsigned long long)points);
-        }
-    }
 #ifdef GTSC_STAMP
     wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
     if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; a.out_npoints[s + 7] = tk_land; }
@@ -1549,54 +1527,27 @@ __global__ __launch_bounds__(256) void compact_copy_kernel(uint64_t nseries, con
 // ------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------
-static bool use_direct_kernels()
-{
-    static const bool v = [] { const char* e = getenv("GTSC_KERNEL"); return e && !strcmp(e, "direct"); }();
-    return v;
-}
-
-// Blocks of at least this many points go to the wave-per-block kernels: a lane-per-series wave
-// walks its 64 blocks in lock step, so a long block keeps its lane (and the 63 beside it) busy for
-// its whole length, while a wave-per-block kernel spends its per-block set-up on too few points
-// when blocks are short.  GTSC_LONG_POINTS overrides the threshold (tests: 0 sends every block
-// to the wave-per-block kernels, a huge number none).
-static uint64_t long_points()
-{
-    static const uint64_t v = [] {
-        const char* e = getenv("GTSC_LONG_POINTS");
-        return e ? strtoull(e, nullptr, 10) : 1024ull;
-    }();
-    return v;
-}
-
-// From how many long blocks of sparse streams on a batch goes to the lane-per-series compressor
-// (GTSC_SPARSE_TILED_MIN overrides it; tests).
-static uint64_t sparse_tiled_min()
-{
-    static const uint64_t v = [] {
-        const char* e = getenv("GTSC_SPARSE_TILED_MIN");
-        return e ? strtoull(e, nullptr, 10) : 57344ull;
-    }();
-    return v;
-}
-
 hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
 {
     if (a0.nseries == 0) return hipSuccess;
     EncodeArgs a = a0;
+    uint32_t none = 0;
+    uint32_t& did = a.dispatch ? *a.dispatch : none;
     a.long_threshold = ~0ull;
     if (a.dfcm_tables) {  // the table look-ups are per-lane global accesses anyway: direct form only
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
+        did |= DISPATCH_LANE_DIRECT;
         hipLaunchKernelGGL((encode_direct_kernel<FMT_V2, PRED_DFCM>), dim3(blocks), dim3(256), 0, stream, a);
-    } else if (use_direct_kernels()) {
+    } else if (a.tun.direct) {
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
+        did |= DISPATCH_LANE_DIRECT;
         if (format == FMT_V2) hipLaunchKernelGGL(encode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(encode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
-    } else if (!a.pts.off && a.pts.uniform >= long_points() && !(a.sparse && a.nseries >= sparse_tiled_min())) {
-        // a uniform batch of long blocks: all of it is the wave-per-block kernel's -- unless the streams are
-        // sparse and the blocks many: a lane per series then skips their runs of unchanged points and is
-        // the faster one once the lanes fill the machine (65,536 x 7,200 gauges: 1.53 against 1.90 ms)
+    } else if (!a.pts.off && a.pts.uniform >= a.tun.long_points && !(a.tun.sparse_hint && a.nseries >= a.tun.sparse_encode_min)) {
+        // a uniform batch of long blocks: all of it is the wave-per-block kernel's -- unless the caller says the
+        // streams are sparse and the blocks are many: a lane per series then skips their runs of unchanged points and
+        // is the faster one once the lanes fill the machine (65,536 x 7,200 gauges: 1.53 against 1.90 ms)
         a.long_threshold = 0;
         return launch_encode_blocks(a, format, stream);
     } else {
@@ -1604,19 +1555,19 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
         // taking the series on its side of the threshold.
         const bool mixed = a.pts.off != nullptr;
         if (mixed) {
-            a.long_threshold = long_points();
+            a.long_threshold = a.tun.long_points;
             if (hipError_t e = launch_encode_blocks(a, format, stream)) return e;
-            if (a.long_threshold == 0) return hipSuccess;  // forced: nothing is left for the lanes
+            if (a.long_threshold == 0) return hipSuccess;  // every block is "long": nothing is left for the lanes
         }
         EncodeArgs g = a;
-        static const bool no_run_skip = [] { const char* e = getenv("GTSC_RUN_SKIP"); return e && !strcmp(e, "0"); }();  // tests
-        g.run_skip = no_run_skip ? 0u : 1u;
+        g.run_skip = a.tun.run_skip;
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
         // Arrays on different phases of a 128-byte line take the SPLIT form: needed when the addresses differ
         // by an odd number of 8-byte words, and the better one for any other difference, because its value loads
         // are cached ones (a row's 128 bytes of values then span two lines, each of which two chunks read).
         const bool split = (((uintptr_t)a.ts ^ (uintptr_t)a.val) & 120u) != 0;
+        did |= DISPATCH_LANE_TILED | (split ? DISPATCH_SPLIT : 0u);
         if (format == FMT_V2) {
             if (split) hipLaunchKernelGGL((encode_tiled_kernel<FMT_V2, true>), dim3(blocks), dim3(64), 0, stream, g);
             else       hipLaunchKernelGGL((encode_tiled_kernel<FMT_V2, false>), dim3(blocks), dim3(64), 0, stream, g);
@@ -1628,9 +1579,6 @@ hipError_t launch_encode(const EncodeArgs& a0, int format, hipStream_t stream)
     return hipGetLastError();
 }
 
-// The wave-per-block decompressor finds the starts of a block's points speculatively, which costs several
-// times the instructions per point of a lane-per-series wave: it pays while the long blocks of a batch are
-// too few to fill the machine with lanes (GTSC_LONG_DECODE_MAX overrides the count).
 // Dense streams decode faster from 16-word rings, but a compute unit holds 7 such waves against 8 with
 // 8-word rings.  When a batch is only a few rounds of waves (long series: a wave lives for
 // milliseconds), what counts is how the waves fill the rounds: 4,096 waves are two full rounds of 8 per
@@ -1652,65 +1600,64 @@ static bool deep_ring_pays(uint32_t waves)
     return cost(7u * units, 0.62) <= cost(8u * units, 1.0);
 }
 
-// Up to how many long blocks a batch is decoded by the wave-per-block kernel.  That kernel's time grows
-// with the number of blocks (0.09-0.18 us per 7,200-point block with all units busy for streams it
-// reads in strides or runs, 0.9 us for one of irregular long points), the lane-per-series kernel's does
-// not until every SIMD has a wave (it is the time one lane needs for its series, 0.4 us per 1,000
-// points).  The break-even count goes with the points the kernel finds per step -- about a thousand
-// blocks per point -- so the caller passes a figure made from what the kernel reported about the
-// batches before (DecodeArgs::stats[2]); without one, 20,480 -- the kernel then runs and reports, and a
-// context whose streams it handles badly pays for that once.
-static uint64_t long_decode_max(const DecodeArgs& a)
-{
-    static const char* const e = getenv("GTSC_LONG_DECODE_MAX");
-    static const uint64_t forced = e ? strtoull(e, nullptr, 10) : 0;
-    return e ? forced : a.long_blocks_max ? a.long_blocks_max : 20480ull;
-}
-
+// Which kernels decode a batch follows from the batch alone.  Series with a capacity of at least long_points points
+// ("long" blocks) may get a wave or a workgroup each instead of a lane: plan_decode_kernel counts them and measures
+// their density on the device, and every kernel launched here asks block_owner() about each series -- the three
+// kernels run over the batch one after the other, and each takes its own blocks.  A uniform batch of short series (the
+// headline workload) launches the lane-per-series kernel alone.
 hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
 {
     if (a0.nseries == 0) return hipSuccess;
     DecodeArgs a = a0;
-    a.long_threshold = ~0ull; a.long_count = nullptr; a.long_max_series = 0;
-    if (!a.dfcm_tables && !use_direct_kernels()) {
-        if (!a.pts.off) {
-            if (a.pts.uniform >= long_points() && a.nseries <= long_decode_max(a)) {
-                a.long_threshold = 0;  // a uniform batch of few long blocks: all of it is the wave-per-block kernel's
-                return launch_decode_blocks(a, format, stream);
-            }
-        } else if (a.long_count_buf) {
-            // per-series capacities are only known on the device: count the long ones, then both kernels
-            // run over the batch and each takes its side
-            a.long_threshold = long_points();
-            a.long_max_series = long_decode_max(a);
-            a.long_count = a.long_count_buf;
-            if (hipError_t e = launch_count_long(a.nseries, a.pts, a.long_threshold, a.long_count_buf, stream)) return e;
-            if (hipError_t e = launch_decode_blocks(a, format, stream)) return e;
-        }
+    uint32_t none = 0;
+    uint32_t& did = a.dispatch ? *a.dispatch : none;
+    a.long_threshold = ~0ull; a.plan = nullptr; a.ring_by_plan = 0;
+    const bool plain = a.dfcm_tables || a.tun.direct;
+    const bool may_be_long = !plain && a.plan_buf && (a.pts.off ? true : a.pts.uniform >= a.tun.long_points);
+    const bool ring_auto = !plain && a.plan_buf && a.tun.decode_ring == 0;
+    if (may_be_long || ring_auto) {
+        if (hipError_t e = launch_decode_plan(a, stream)) return e;
+        a.plan = a.plan_buf;
+    }
+    if (may_be_long) {
+        a.long_threshold = a.tun.long_points;
+        // (a uniform batch: the host knows how many long blocks there are, and which kernels cannot get any)
+        const uint64_t nlong = a.pts.off ? ~0ull : a.nseries;
+        const bool wg_possible = a.pts.off || nlong <= a.tun.wg_decode_max || (a.pts.uniform >= a.tun.vlong_points && nlong <= a.tun.wg_decode_vlong_max);
+        const uint64_t wave_most = a.tun.wave_decode_max > a.tun.wave_decode_max_dense ? a.tun.wave_decode_max : a.tun.wave_decode_max_dense;
+        const bool wave_possible = a.pts.off || nlong <= wave_most;
+        if (wg_possible) if (hipError_t e = launch_decode_blocks_wg(a, format, stream)) return e;
+        if (wave_possible) if (hipError_t e = launch_decode_blocks(a, format, stream)) return e;
+        if (!a.pts.off && a.tun.long_points == 0 && a.tun.wave_decode_max >= a.nseries && a.tun.wave_decode_max_dense >= a.nseries)
+            return hipGetLastError();  // every block is "long" and a wave or workgroup takes it whatever the plan says: nothing is left for the lanes
     }
     if (a.dfcm_tables) {
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
+        did |= DISPATCH_LANE_DIRECT;
         hipLaunchKernelGGL((decode_direct_kernel<FMT_V2, PRED_DFCM>), dim3(blocks), dim3(256), 0, stream, a);
-    } else if (use_direct_kernels()) {
+    } else if (a.tun.direct) {
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);
+        did |= DISPATCH_LANE_DIRECT;
         if (format == FMT_V2) hipLaunchKernelGGL(decode_direct_kernel<FMT_V2>, dim3(blocks), dim3(256), 0, stream, a);
         else                  hipLaunchKernelGGL(decode_direct_kernel<FMT_V1>, dim3(blocks), dim3(256), 0, stream, a);
     } else {
         DecodeArgs g = a;
         g.group_shift = group_shift_of(a.pts);
         const uint32_t blocks = grouped_blocks(a.nseries, g.group_shift);
-        static const int forced = [] { const char* e = getenv("GTSC_RING"); return e ? atoi(e) : 0; }();  // tests: 8 or 16
-        static const bool no_run_skip = [] { const char* e = getenv("GTSC_RUN_SKIP"); return e && !strcmp(e, "0"); }();  // tests
-        g.run_skip = no_run_skip ? 0u : 1u;
-        bool deep = forced ? forced == 16 : a.deep_ring != 0;
-        if (!forced && a.deep_ring == 1) deep = deep_ring_pays(blocks);
+        g.run_skip = a.tun.run_skip;
+        g.ring_by_plan = ring_auto ? 1u : 0u;
+        // 16-word rings where asked for -- unless the batch is so few rounds of waves that 8 per unit beat 7 (see above)
+        const bool deep = a.tun.decode_ring == 16 && deep_ring_pays(blocks);
+        const bool both = ring_auto && deep_ring_pays(blocks);
+        did |= DISPATCH_LANE_TILED | (both ? DISPATCH_LANE_BOTH_RINGS : deep ? DISPATCH_LANE_RING16 : 0u);
+        if (!both) g.ring_by_plan = 0;
         if (format == FMT_V2) {
-            if (deep) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 16>), dim3(blocks), dim3(64), 0, stream, g);
-            else      hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 8>), dim3(blocks), dim3(64), 0, stream, g);
+            if (deep || both) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 16>), dim3(blocks), dim3(64), 0, stream, g);
+            if (!deep)        hipLaunchKernelGGL((decode_tiled_kernel<FMT_V2, 8>), dim3(blocks), dim3(64), 0, stream, g);
         } else {
-            if (deep) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V1, 16>), dim3(blocks), dim3(64), 0, stream, g);
-            else      hipLaunchKernelGGL((decode_tiled_kernel<FMT_V1, 8>), dim3(blocks), dim3(64), 0, stream, g);
+            if (deep || both) hipLaunchKernelGGL((decode_tiled_kernel<FMT_V1, 16>), dim3(blocks), dim3(64), 0, stream, g);
+            if (!deep)        hipLaunchKernelGGL((decode_tiled_kernel<FMT_V1, 8>), dim3(blocks), dim3(64), 0, stream, g);
         }
     }
     return hipGetLastError();

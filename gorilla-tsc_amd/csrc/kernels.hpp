@@ -8,6 +8,25 @@
 
 namespace gtsc {
 
+// What a context lets its caller tune (gtsc_set_tunable; the environment variable named with each, if set when
+// the context is created, replaces the default).  Nothing here changes results, only which kernel produces them.
+struct Tunables {
+    uint64_t long_points = 1024;           // blocks of at least this many points are "long": a wave or workgroup per block may take them
+    uint64_t vlong_points = 16384;         // ... and from this many on "very long"
+    uint64_t wave_decode_max = 12288;      // batches of up to this many long blocks: the wave-per-block decompressor takes them
+    uint64_t wave_decode_max_dense = 2048; // the same when the long blocks' images come to more than dense_bits per point
+    uint64_t wg_decode_max = 256;          // batches of up to this many long blocks: the sparse ones get a workgroup each
+    uint64_t wg_decode_vlong_max = 512;    // batches of up to this many very long blocks: the sparse ones among those get a workgroup each
+    uint32_t wg_dense_bits = 40;           // a block counts as sparse below this many compressed bits per point of capacity
+    uint32_t dense_bits = 64;              // see wave_decode_max_dense
+    uint64_t sparse_encode_min = 57344;    // batches of at least this many long blocks of sparse streams: the lane-per-series compressor
+    uint64_t coop_encode_max = 384;        // batches of up to this many long blocks: the compressor gives each a workgroup
+    uint32_t sparse_hint = 0;              // 1: the streams to compress are sparse (a few bits per point)
+    uint32_t decode_ring = 8;              // input rings of the lane-per-series decompressor: 8 or 16 words; 0 = by the batch's density
+    uint32_t run_skip = 1;                 // 0: the lane-per-series kernels keep to their lock-step loops
+    uint32_t direct = 0;                   // 1: the plain lane-per-series kernels only
+};
+
 struct EncodeArgs {
     uint64_t nseries;
     const int64_t* block_ts;
@@ -28,10 +47,17 @@ struct EncodeArgs {
     // kernel and left alone by the lane-per-series kernels (~0: no such series)
     uint64_t long_threshold;
     uint32_t run_skip;     // set by the launcher: the tiled kernel may code chunks by run skipping (see encode_tiled_kernel)
-    // from the caller: what the streams compressed before looked like -- 1 = a few bits per point (long blocks of such
-    // streams are then left to the lane-per-series kernel when the batch is large), 0 = dense or unknown
-    uint32_t sparse;
-    uint64_t* stats;       // may be null: [3] += words written, [4] += points coded (a sample of the blocks)
+    Tunables tun;          // from the caller
+    uint32_t* dispatch;    // from the caller, host memory, may be null: receives the DISPATCH_* bits of the kernels enqueued
+};
+
+// What a batch of images looks like, worked out on the device before the decompressors start (plan_decode_kernel):
+// every kernel of the batch reads it and they agree on who takes which block.
+struct DecodePlan {
+    uint64_t nlong, nvlong;          // series with a capacity of at least long_points / vlong_points points
+    uint64_t words_long, cap_long;   // the long ones' image words and capacities, summed
+    uint64_t words_all, cap_all;     // the same over every 64th series of the batch
+    uint64_t pad[2];
 };
 
 struct DecodeArgs {
@@ -48,26 +74,48 @@ struct DecodeArgs {
     int64_t* dfcm_tables;     // as in EncodeArgs
     uint32_t dfcm_mask;
     uint32_t group_shift;     // as in EncodeArgs
-    uint32_t deep_ring;       // the tiled kernel's input rings: 0 = 8 words; 1 = the streams are dense, 16 words unless the batch's waves fill the units better with 8; 2 = 16 words
-    uint64_t* stats;          // may be null: [0] += words read, [1] += points stored (a sample of the waves); [2] += steps | points << 32 of a sample of the wave-per-block kernel's blocks
-    // Series whose capacity is at least long_threshold points are decoded by the wave-per-block kernel and left
-    // alone by the lane-per-series kernels (~0: none) -- provided the batch holds at most long_max_series of
-    // them, which both kernels read from *long_count (null: no such condition).  Set by the launcher.
+    // Series whose capacity is at least long_threshold points may be decoded a wave or a workgroup per block
+    // (~0: none; set by the launcher); block_owner() says which kernel takes one, from the plan.
     uint64_t long_threshold;
-    const uint64_t* long_count;
-    uint64_t long_max_series;
-    uint64_t* long_count_buf; // from the caller: one device word the launcher may use for the count (may be null)
-    uint64_t long_blocks_max; // from the caller: up to how many long blocks a batch goes to the wave-per-block kernel (0: the built-in figure)
+    const DecodePlan* plan;   // set by the launcher (null: no long blocks, and the ring is not chosen by density)
+    DecodePlan* plan_buf;     // from the caller: device memory for the plan
     uint32_t run_skip;        // set by the launcher: the 8-word form may decode chunks by run skipping (see decode_tiled_kernel)
+    uint32_t ring_by_plan;    // set by the launcher: the lane-per-series kernel runs in both ring forms and the plan says which one works
+    Tunables tun;             // from the caller
+    uint32_t* dispatch;       // as in EncodeArgs
 };
+
+// Which decompressor takes series s: the lane-per-series kernel (a lane), the wave-per-block kernel or the
+// workgroup-per-block kernel.  Sparse streams of few or very long blocks get a workgroup each (it follows the chain
+// of point starts two to three times faster where points are short or irregular); other long blocks get a wave each
+// while the batch holds few enough of them to leave the lanes of the lane-per-series kernel mostly idle -- fewer
+// when the images are dense, because irregular long points are what the wave-per-block kernel is slowest at.
+constexpr int OWNER_LANE = 0, OWNER_WAVE = 1, OWNER_WG = 2;
+__device__ __forceinline__ int block_owner(const DecodeArgs& a, uint64_t s)
+{
+    const uint64_t cap = a.pts.size(s);
+    if (cap < a.long_threshold) return OWNER_LANE;
+    const DecodePlan& pl = *a.plan;
+    const uint64_t nw = a.in_nwords ? a.in_nwords[s] : a.slots.size(s);
+    const bool sparse = nw * 64 < cap * a.tun.wg_dense_bits;
+    if (sparse && (pl.nlong <= a.tun.wg_decode_max || (cap >= a.tun.vlong_points && pl.nvlong <= a.tun.wg_decode_vlong_max))) return OWNER_WG;
+    const bool dense_batch = pl.words_long * 64 > pl.cap_long * a.tun.dense_bits;
+    return pl.nlong <= (dense_batch ? a.tun.wave_decode_max_dense : a.tun.wave_decode_max) ? OWNER_WAVE : OWNER_LANE;
+}
 
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);
 // wave-per-block compressor over the series of `a` with at least a.long_threshold points (block_codec.hip)
 hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
-// wave-per-block decompressor and the count of long series it shares with the lane-per-series kernels (block_codec.hip)
+// wave-per-block decompressor (block_codec.hip) and workgroup-per-block decompressor (block_decode_wg.hip): each
+// takes the series of `a` that block_owner() gives it
 hipError_t launch_decode_blocks(const DecodeArgs& a, int format, hipStream_t stream);
-hipError_t launch_count_long(uint64_t nseries, Layout pts, uint64_t long_threshold, uint64_t* count, hipStream_t stream);
+hipError_t launch_decode_blocks_wg(const DecodeArgs& a, int format, hipStream_t stream);
+// fills a.plan_buf (block_codec.hip)
+hipError_t launch_decode_plan(const DecodeArgs& a, hipStream_t stream);
+// Which kernels a launcher enqueued, for gtsc_last_dispatch(): the values of GTSC_DISPATCH_* in include/gtsc.h
+constexpr uint32_t DISPATCH_LANE_DIRECT = 1u, DISPATCH_LANE_TILED = 2u, DISPATCH_LANE_RING16 = 4u, DISPATCH_LANE_BOTH_RINGS = 8u,
+                   DISPATCH_WAVE = 16u, DISPATCH_WG = 32u, DISPATCH_PLAN = 64u, DISPATCH_COOP = 128u, DISPATCH_SPLIT = 256u;
 
 // out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); scratch holds
 // scan_scratch_words(n) words.

@@ -45,10 +45,36 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     v += dpp_move<0x143, 0xC>(0u, v);
     return v;
 }
+// x with lane `lane` (wave-uniform) replaced by the wave-uniform value v: v_writelane_b32 (this compiler has no
+// builtin of that name; the declaration binds the intrinsic itself)
+extern "C" __device__ int gtsc_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane");
+__device__ __forceinline__ uint32_t write_lane(uint32_t x, uint32_t v, uint32_t lane) { return (uint32_t)gtsc_llvm_writelane((int)v, (int)lane, (int)x); }
 __device__ __forceinline__ uint32_t read_lane(uint32_t x, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)lane); }
 __device__ __forceinline__ uint64_t read_lane(uint64_t x, uint32_t lane)
 {
     return ((uint64_t)read_lane((uint32_t)(x >> 32), lane) << 32) | read_lane((uint32_t)x, lane);
+}
+
+// inclusive prefix sum / xor of 64-bit values over the wave (all 64 lanes active; lanes without a
+// value contribute zero)
+template <bool XOR>
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v)
+{
+#define GTSC_SCAN_STEP(CTRL, RM)                                                               \
+    {                                                                                          \
+        const uint32_t lo_ = dpp_move<CTRL, RM>(0u, (uint32_t)v);                              \
+        const uint32_t hi_ = dpp_move<CTRL, RM>(0u, (uint32_t)(v >> 32));                      \
+        const uint64_t o_ = ((uint64_t)hi_ << 32) | lo_;                                       \
+        v = XOR ? (v ^ o_) : (v + o_);                                                         \
+    }
+    GTSC_SCAN_STEP(0x111, 0xF)
+    GTSC_SCAN_STEP(0x112, 0xF)
+    GTSC_SCAN_STEP(0x114, 0xF)
+    GTSC_SCAN_STEP(0x118, 0xF)
+    GTSC_SCAN_STEP(0x142, 0xA)
+    GTSC_SCAN_STEP(0x143, 0xC)
+#undef GTSC_SCAN_STEP
+    return v;
 }
 
 }  // namespace gtsc

@@ -23,7 +23,14 @@ SYMBOLS = (
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
     "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
     "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex", "gtsc_compact_device_noalloc", "gtsc_set_decode_ring",
+    "gtsc_set_tunable", "gtsc_get_tunable", "gtsc_last_dispatch", "gtsc_host_pipeline_idle",
 )
+# gtsc_set_tunable ids and gtsc_last_dispatch bits (include/gtsc.h)
+(TUNE_LONG_POINTS, TUNE_VLONG_POINTS, TUNE_WAVE_DECODE_MAX, TUNE_WAVE_DECODE_MAX_DENSE, TUNE_WG_DECODE_MAX, TUNE_WG_DECODE_VLONG_MAX,
+ TUNE_WG_DENSE_BITS, TUNE_DENSE_BITS, TUNE_SPARSE_ENCODE_MIN, TUNE_COOP_ENCODE_MAX, TUNE_SPARSE_HINT, TUNE_DECODE_RING, TUNE_RUN_SKIP,
+ TUNE_DIRECT_KERNELS) = range(1, 15)
+(DISPATCH_LANE_DIRECT, DISPATCH_LANE_TILED, DISPATCH_LANE_RING16, DISPATCH_LANE_BOTH_RINGS, DISPATCH_WAVE, DISPATCH_WG, DISPATCH_PLAN,
+ DISPATCH_COOP, DISPATCH_SPLIT) = (1 << i for i in range(9))
 NOALLOC_MAX_SERIES = 8_000_000
 PRED_LAST, PRED_DFCM = 0, 1
 ENC_NO_CLOSE = 1
@@ -69,6 +76,14 @@ def lib():
     L.gtsc_set_predictor.argtypes = [vp, i32, i32]
     L.gtsc_set_decode_ring.restype = i32
     L.gtsc_set_decode_ring.argtypes = [vp, i32]
+    L.gtsc_set_tunable.restype = i32
+    L.gtsc_set_tunable.argtypes = [vp, i32, u64]
+    L.gtsc_get_tunable.restype = i32
+    L.gtsc_get_tunable.argtypes = [vp, i32, C.POINTER(u64)]
+    L.gtsc_last_dispatch.restype = i32
+    L.gtsc_last_dispatch.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(u64)]
+    L.gtsc_host_pipeline_idle.restype = i32
+    L.gtsc_host_pipeline_idle.argtypes = [vp]
     L.gtsc_sync.restype = i32
     L.gtsc_sync.argtypes = [vp]
     L.gtsc_encode_device.restype = i32
@@ -158,6 +173,28 @@ class Context:
 
     def set_decode_ring(self, ring_words):
         _check(lib().gtsc_set_decode_ring(self._h, int(ring_words)))
+
+    def set_tunable(self, which, value):
+        _check(lib().gtsc_set_tunable(self._h, int(which), int(value)))
+
+    def get_tunable(self, which):
+        v = C.c_uint64()
+        _check(lib().gtsc_get_tunable(self._h, int(which), C.byref(v)))
+        return int(v.value)
+
+    def last_dispatch(self, with_plan=False):
+        """Bits of the kernels the last device call enqueued (DISPATCH_*); with_plan: also what the device
+        made of the last decoded batch, as a list of six counts (waits for the stream)."""
+        k = C.c_uint32()
+        plan = (C.c_uint64 * 6)() if with_plan else None
+        _check(lib().gtsc_last_dispatch(self._h, C.byref(k), plan))
+        return (int(k.value), [int(x) for x in plan]) if with_plan else int(k.value)
+
+    def host_pipeline_idle(self):
+        rc = lib().gtsc_host_pipeline_idle(self._h)
+        if rc < 0:
+            _check(rc)
+        return bool(rc)
 
     def sync(self):
         try:

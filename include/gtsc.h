@@ -93,17 +93,72 @@ int gtsc_destroy(gtsc_ctx *ctx);
 int gtsc_set_predictor(gtsc_ctx *ctx, int predictor, int table_size);
 
 /*
- * Which form of the lane-per-series decompressor gtsc_decode_device uses.  It exists with input rings
- * of 8 words per series (fastest on streams of a few bits per point) and of 16 words (fastest on
- * streams of tens of bits per point); results are identical, only the speed differs.
- * ring_words = 0 (the default): chosen from what the context decoded before its last gtsc_sync()
- * -- above 40 compressed bits per point the 16-word form -- so the first decode after
- * gtsc_create() uses 8, and a change of density takes effect one sync later.
- * ring_words = 8 or 16: always that form (a benchmark, or a caller that knows its data).
- * gtsc_decode_host knows each chunk's density beforehand and needs no hint.
+ * Tunables.  Which kernel codes a batch is decided from the batch itself -- its layout, the number and length of
+ * its long blocks and the density of their images, the last two worked out on the device before the kernels start --
+ * never from what the context coded before: a fresh context and one with history choose alike.  The thresholds of
+ * those decisions are per-context tunables; results never depend on them, only speed.  Each has a default, which an
+ * environment variable (read when the context is created) or gtsc_set_tunable() replaces.  No reference counterpart.
+ *
+ *   GTSC_TUNE_LONG_POINTS (GTSC_LONG_POINTS, 1024): blocks of at least this many points ("long" blocks) may get a
+ *     wavefront or a workgroup each instead of one lane of a wavefront that walks 64 blocks in lock step.
+ *   GTSC_TUNE_VLONG_POINTS (GTSC_VLONG_POINTS, 16384): from this many points on a block is "very long".
+ *   GTSC_TUNE_WG_DECODE_MAX (GTSC_WG_DECODE_MAX, 256) / GTSC_TUNE_WG_DECODE_VLONG_MAX (GTSC_WG_DECODE_VLONG_MAX, 512):
+ *     in batches of up to that many long / very long blocks, the long / very long blocks whose images are sparse are
+ *     decompressed a workgroup per block; GTSC_TUNE_WG_DENSE_BITS (GTSC_WG_DENSE_BITS, 40): sparse = fewer
+ *     compressed bits per point of capacity than this.
+ *   GTSC_TUNE_WAVE_DECODE_MAX (GTSC_LONG_DECODE_MAX, 12288): in batches of up to that many long blocks the other
+ *     long blocks are decompressed a wavefront per block; GTSC_TUNE_WAVE_DECODE_MAX_DENSE (GTSC_LONG_DECODE_MAX_DENSE,
+ *     2048): the limit when the long blocks' images come to more than GTSC_TUNE_DENSE_BITS (GTSC_DENSE_BITS, 64)
+ *     bits per point.  Beyond the limit every block has a lane.
+ *   GTSC_TUNE_COOP_ENCODE_MAX (GTSC_COOP_MAX, 384): batches of up to that many long blocks are compressed a workgroup
+ *     per block, larger ones a wavefront per block.
+ *   GTSC_TUNE_SPARSE_HINT (GTSC_SPARSE_HINT, 0): 1 tells the compressor that the streams are sparse (a few bits per
+ *     point: mostly unchanged values at a regular interval); batches of at least GTSC_TUNE_SPARSE_ENCODE_MIN
+ *     (GTSC_SPARSE_TILED_MIN, 57344) long blocks are then compressed a lane per block, which skips runs of such points.
+ *   GTSC_TUNE_DECODE_RING (GTSC_RING, 8): the lane-per-series decompressor exists with input rings of 8 words per
+ *     series (fastest on streams of a few bits per point) and of 16 words (3-10 % faster on streams of tens of bits
+ *     per point); 0 = the batch's density decides, on the device: both forms are launched and one of them returns
+ *     at once (about 10 us per call).  gtsc_decode_host knows each chunk's density beforehand and treats 0 as "by density" at no cost.
+ *   GTSC_TUNE_RUN_SKIP (GTSC_RUN_SKIP, 1): 0 keeps the lane-per-series kernels on their lock-step loops.
+ *   GTSC_TUNE_DIRECT_KERNELS (GTSC_DIRECT, 0): 1 selects the plain lane-per-series kernels (no LDS staging) for everything.
+ *
+ * gtsc_set_decode_ring(ctx, n) is gtsc_set_tunable(ctx, GTSC_TUNE_DECODE_RING, n).
+ */
+#define GTSC_TUNE_LONG_POINTS            1
+#define GTSC_TUNE_VLONG_POINTS           2
+#define GTSC_TUNE_WAVE_DECODE_MAX        3
+#define GTSC_TUNE_WAVE_DECODE_MAX_DENSE  4
+#define GTSC_TUNE_WG_DECODE_MAX          5
+#define GTSC_TUNE_WG_DECODE_VLONG_MAX    6
+#define GTSC_TUNE_WG_DENSE_BITS          7
+#define GTSC_TUNE_DENSE_BITS             8
+#define GTSC_TUNE_SPARSE_ENCODE_MIN      9
+#define GTSC_TUNE_COOP_ENCODE_MAX       10
+#define GTSC_TUNE_SPARSE_HINT           11
+#define GTSC_TUNE_DECODE_RING           12
+#define GTSC_TUNE_RUN_SKIP              13
+#define GTSC_TUNE_DIRECT_KERNELS        14
+int gtsc_set_tunable(gtsc_ctx *ctx, int which, uint64_t value);
+int gtsc_get_tunable(gtsc_ctx *ctx, int which, uint64_t *value);
+int gtsc_set_decode_ring(gtsc_ctx *ctx, int ring_words);
+
+/*
+ * Diagnostic: which kernels the context's last gtsc_encode_device(_ex) / gtsc_decode_device call enqueued (bits
+ * below; the kernels that find no block of theirs in the batch return at once), and -- plan != NULL, decode only,
+ * waits for the context's stream -- what the device made of that batch: plan[0] long blocks, [1] very long ones,
+ * [2] image words and [3] capacity of the long ones, [4] image words and [5] capacity of every 64th series.
  * No reference counterpart.
  */
-int gtsc_set_decode_ring(gtsc_ctx *ctx, int ring_words);
+#define GTSC_DISPATCH_LANE_DIRECT      1u  /* plain lane-per-series kernel */
+#define GTSC_DISPATCH_LANE_TILED       2u  /* lane-per-series kernel with LDS staging */
+#define GTSC_DISPATCH_LANE_RING16      4u  /* ... its decompressor with 16-word input rings */
+#define GTSC_DISPATCH_LANE_BOTH_RINGS  8u  /* ... in both forms, the device choosing */
+#define GTSC_DISPATCH_WAVE            16u  /* wavefront-per-block kernel */
+#define GTSC_DISPATCH_WG              32u  /* workgroup-per-block decompressor */
+#define GTSC_DISPATCH_PLAN            64u  /* the kernel that works out the plan */
+#define GTSC_DISPATCH_COOP           128u  /* workgroup-per-block compressor */
+#define GTSC_DISPATCH_SPLIT          256u  /* the compressor's form for arrays on different phases of a 128-byte line */
+int gtsc_last_dispatch(gtsc_ctx *ctx, uint32_t *kernels, uint64_t plan[6]);
 
 /* Enqueue on a caller-owned hipStream_t instead of the context's own
  * (NULL restores the context's stream). */
@@ -241,8 +296,11 @@ int gtsc_compact_device_noalloc(gtsc_ctx *ctx, uint64_t nseries,
 /*
  * Host-memory forms: every pointer is host memory and the call returns when
  * the results are in the caller's arrays.  The batch is cut into chunks of
- * whole series; each chunk is copied in on one stream, coded and copied out on one of two
- * more that take turns, so that copies overlap kernels and each other.  Host arrays obtained
+ * whole series that pass through three streams -- one for all copies in (two chunks ahead of the kernels), one for
+ * the kernels (and the compressor's copy out, which the host can only enqueue once it knows the chunk's size), one
+ * for the decompressor's copies out -- and three sets of device buffers that the chunks take in turn, tied together
+ * by events, so that copies overlap kernels and each other.  Whatever the return code, nothing of the call is in
+ * flight any more when it returns: the caller may free or reuse its arrays.  Host arrays obtained
  * from gtsc_host_alloc() are page-locked and move by DMA at PCIe rate; other
  * memory works but is staged by the HIP runtime.
  *
@@ -280,6 +338,10 @@ int gtsc_decode_host(gtsc_ctx *ctx, int format, uint64_t nseries,
                      int64_t *ts, uint64_t *val,
                      const uint64_t *pt_off, uint64_t uniform_capacity,
                      uint64_t *out_npoints, uint32_t *status);
+
+/* Diagnostic: 1 when none of the streams of the host entry points has work in flight, 0 when one has,
+ * negative on error.  (After any host entry point has returned it is 1.)  No reference counterpart. */
+int gtsc_host_pipeline_idle(gtsc_ctx *ctx);
 
 /* Page-locked host memory for the host entry points (hipHostMalloc/hipHostFree). */
 void *gtsc_host_alloc(size_t bytes);

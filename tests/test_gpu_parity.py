@@ -668,38 +668,6 @@ def test_lock_step_decoder_in_its_own_process():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_sparse_long_blocks_after_a_sync(ctx):
-    """Once a context has seen sparse streams (gtsc_sync reads the density counters), uniform batches of long
-    blocks go to the lane-per-series compressor when they hold many blocks.  GTSC_SPARSE_TILED_MIN=0 makes "many"
-    any number (read once per process: the test runs itself in a child): the same batch compressed before and
-    after the sync -- by the wave-per-block kernel, then by the lane-per-series kernel -- gives the oracle's words
-    both times, in both formats, and decodes to its input."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("GTSC_SPARSE_TILED_MIN") != "0":
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-                            "-k", "sparse_long_blocks_after_a_sync"], env=dict(os.environ, GTSC_SPARSE_TILED_MIN="0"),
-                           capture_output=True, text=True, timeout=300, cwd=root)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-        return
-    for gfmt, ofmt in FMTS:
-        fresh = G.Context(0)
-        try:
-            b = synth.gauge_integer(S=700, P=3000, seed=21)
-            for _ in range(3):  # the first call knows nothing about the streams; the later ones do
-                out, off, nw, d_out, d_nw = check_encode_against_oracle(fresh, b, gfmt, ofmt, uniform=True)
-                ts, val, npts, st, rc = gpu_decode(fresh, out, off, nw, b.pt_off, gfmt, uniform_cap=3000, d_words=d_out)
-                assert rc == 0 and not st.any()
-                assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
-            dense = synth.random_walk(S=300, P=2000)  # a dense batch right after: the choice made for sparse streams
-            check_encode_against_oracle(fresh, dense, gfmt, ofmt, uniform=True)
-            check_encode_against_oracle(fresh, dense, gfmt, ofmt, uniform=True)
-        finally:
-            fresh.close()
-
-
 def test_lane_per_series_kernels_in_their_own_process():
     """The plain lane-per-series kernels (both formats) are what GTSC_KERNEL=direct selects; the choice is read
     once per process, so the sweep runs in a child process for a few seconds."""
@@ -715,7 +683,8 @@ def test_lane_per_series_kernels_in_their_own_process():
 
 def test_decode_ring_choice_is_explicit(ctx):
     """gtsc_set_decode_ring pins the form of the lane-per-series decompressor (8- or 16-word input rings):
-    same points, counts and status either way, on sparse and on dense streams; 0 gives the choice back."""
+    same points, counts and status either way, on sparse and on dense streams; with 0 both forms are launched and
+    the batch's density, measured on the device, says which of them works."""
     try:
         for b in (synth.gauge_integer(S=3000, P=120), synth.adversarial(S=200, P=700)):
             out, off, nw, _, _ = check_encode_against_oracle(ctx, b, G.FMT_V2, O.V2, uniform=True)
@@ -725,23 +694,27 @@ def test_decode_ring_choice_is_explicit(ctx):
                 ts, val, npts, st, rc = gpu_decode(ctx, out, off, nw, b.pt_off, G.FMT_V2, uniform_cap=b.uniform_npoints())
                 assert rc == 0 and not st.any()
                 assert np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+                k = ctx.last_dispatch()
+                assert bool(k & G.DISPATCH_LANE_BOTH_RINGS) == (ring == 0) and bool(k & G.DISPATCH_LANE_RING16) == (ring == 16)
         with pytest.raises(G.GtscError):
             ctx.set_decode_ring(12)
     finally:
-        ctx.set_decode_ring(0)
+        ctx.set_decode_ring(8)
 
 
 def test_wave_per_block_kernels_forced_in_their_own_process():
     """The wave-per-block kernels normally take blocks of 1,024 points and more (the decompressor only in
-    batches of few such blocks; the compressor's workgroup-per-block form batches of up to 384 blocks).  GTSC_LONG_POINTS=0 sends every block to them, whatever its length, and
-    GTSC_LONG_DECODE_MAX lifts the batch limit; both are read once per process, so a child process runs
+    batches of few such blocks; the compressor's workgroup-per-block form batches of up to 384 blocks).  GTSC_LONG_POINTS=0 sends every block to them, whatever its length,
+    GTSC_LONG_DECODE_MAX(_DENSE) lift the batch limits and GTSC_WG_DECODE_MAX=0 keeps the workgroup-per-block
+    decompressor out of it; the variables preset the tunables of every context created in a process, so a child process runs
     the randomised sweep and the parity tests that hold the odd cases (benchmark shapes incl. the 100,000-point
     blocks and skewed lengths, garbage and damaged images, quirks, zero timestamps, slot overflow, capacities)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GTSC_LONG_POINTS="0", GTSC_LONG_DECODE_MAX="1000000000")
+    env = dict(os.environ, GTSC_LONG_POINTS="0", GTSC_LONG_DECODE_MAX="1000000000", GTSC_LONG_DECODE_MAX_DENSE="1000000000",
+               GTSC_WG_DECODE_MAX="0", GTSC_WG_DECODE_VLONG_MAX="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "8", "9000"], env=env,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -46,6 +46,21 @@ def test_noalloc_compaction_equals_the_allocating_one():
         big = compact_both_ways(ctx, synth.ragged_mix(seed=3, nseries=70000, pmax=12))
         small = compact_both_ways(ctx, synth.ragged_mix(seed=4, nseries=900, pmax=40))
         assert big > small > 0
+        # the point of the entry point: it allocates nothing.  The device's free memory is the same before and
+        # after calls on a warm context, for a batch larger than any before (the allocating form grows its
+        # scratch buffer for such a batch; torch's own allocations are made beforehand).
+        S = 300000
+        d_nw = torch.full((S,), 3, dtype=torch.int64, device="cuda")
+        d_slots = torch.zeros(S * 3, dtype=torch.int64, device="cuda")
+        d_c = torch.zeros(S * 3, dtype=torch.int64, device="cuda")
+        d_co = torch.zeros(S + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for _ in range(3):
+            ctx.compact_device(d_slots, d_nw, d_c, d_co, uniform_slot_words=3, noalloc=True)
+        ctx.sync()
+        assert torch.cuda.mem_get_info()[0] == free_before, "gtsc_compact_device_noalloc changed the device's free memory"
+        assert int(d_co[-1]) == 3 * S
         # the limit is enforced before anything is launched
         with pytest.raises(G.GtscError) as ei:
             z = torch.zeros(8, dtype=torch.int64, device="cuda")
