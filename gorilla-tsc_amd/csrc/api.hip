@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gtsc.h"
@@ -810,6 +812,131 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
     if (flags & (ST_TRUNCATED | ST_MALFORMED)) return fail(GTSC_ERR_STREAM, "some images were truncated or malformed (status bits 0x%x)", flags);
     if (flags & ST_OVERFLOW) return fail(GTSC_ERR_CAPACITY, "some series hold more points than their ts/val slot");
     return GTSC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------
+// One batch over several contexts (normally one per GPU of the node).  Series are independent, so the batch is cut
+// into contiguous runs of series with about equal numbers of points, one per context; each run goes through its
+// context's host pipeline on a host thread of its own, and the results land where a single call would have put them.
+// ------------------------------------------------------------------------
+namespace {
+
+// boundaries of n contiguous shards of [0, nseries) with about equal weight (points, or capacity)
+std::vector<uint64_t> shard_bounds(int n, uint64_t nseries, const uint64_t* off, uint64_t uniform)
+{
+    std::vector<uint64_t> b(n + 1, nseries);
+    b[0] = 0;
+    const uint64_t total = off ? off[nseries] - off[0] : nseries * uniform;
+    uint64_t s = 0;
+    for (int k = 1; k < n; k++) {
+        const uint64_t want = off ? off[0] + (total / (uint64_t)n) * (uint64_t)k : 0;
+        if (off) { while (s < nseries && off[s] < want) s++; }
+        else s = nseries * (uint64_t)k / (uint64_t)n;
+        b[k] = s;
+    }
+    return b;
+}
+
+struct ShardResult { int rc = GTSC_OK; std::string err; };
+
+// the worst return code of the shards becomes the call's, with its message
+int merge_shard_results(const std::vector<ShardResult>& r)
+{
+    int rc = GTSC_OK;
+    const ShardResult* worst = nullptr;
+    for (const ShardResult& x : r)
+        if (x.rc != GTSC_OK && (rc == GTSC_OK || x.rc == GTSC_ERR_HIP || x.rc == GTSC_ERR_ARG)) { rc = x.rc; worst = &x; }
+    return worst ? fail(rc, "%s", worst->err.c_str()) : GTSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtsc_encode_host_multi(int nctx, gtsc_ctx* const* ctxs, int format, uint32_t options, uint64_t nseries, const int64_t* block_ts,
+                           const int64_t* ts, const uint64_t* val, const uint64_t* pt_off, uint64_t uniform_npoints,
+                           uint64_t* out_words, uint64_t out_capacity_words, uint64_t* out_off, uint64_t* out_nbits)
+{
+    if (nctx <= 0 || !ctxs) return fail(GTSC_ERR_ARG, "no contexts");
+    for (int k = 0; k < nctx; k++) if (!ctxs[k]) return fail(GTSC_ERR_ARG, "context %d is NULL", k);
+    if (!out_off) return fail(GTSC_ERR_ARG, "out_off must not be NULL");
+    if (nctx == 1 || nseries < (uint64_t)nctx)
+        return gtsc_encode_host_ex(ctxs[0], format, options, nseries, block_ts, ts, val, pt_off, uniform_npoints, out_words,
+                                   out_capacity_words, out_off, out_nbits);
+    if (!block_ts || !out_words) return fail(GTSC_ERR_ARG, "block_ts/out_words must not be NULL");
+    const std::vector<uint64_t> b = shard_bounds(nctx, nseries, pt_off, uniform_npoints);
+    // Where each shard's images go: shard k writes back to back from the place where it would start if every
+    // earlier image had its worst-case size; afterwards the shards are moved together.  (A caller whose buffer is
+    // smaller than the worst case of the whole batch gets private buffers per shard instead.)
+    std::vector<uint64_t> worst(nctx + 1, 0);
+    for (int k = 0; k < nctx; k++) {
+        uint64_t w = 0;
+        for (uint64_t s = b[k]; s < b[k + 1]; s++) w += gtsc_max_words(pt_off ? pt_off[s + 1] - pt_off[s] : uniform_npoints);
+        worst[k + 1] = worst[k] + w;
+    }
+    const bool in_place = worst[nctx] <= out_capacity_words;
+    std::vector<std::vector<uint64_t>> priv(in_place ? 0 : nctx);
+    std::vector<std::vector<uint64_t>> offs(nctx);
+    std::vector<ShardResult> res(nctx);
+    std::vector<std::thread> threads;
+    for (int k = 0; k < nctx; k++) {
+        const uint64_t s0 = b[k], ns = b[k + 1] - b[k];
+        offs[k].assign(ns + 1, 0);
+        uint64_t* dst = out_words + worst[k];
+        uint64_t cap = worst[k + 1] - worst[k];
+        if (!in_place) { priv[k].resize(cap ? cap : 1); dst = priv[k].data(); }
+        threads.emplace_back([=, &offs, &res] {
+            // (offset arrays are absolute: the shard's slice of pt_off still indexes the whole ts/val arrays)
+            const int rc = gtsc_encode_host_ex(ctxs[k], format, options, ns, block_ts + s0, pt_off ? ts : ts + s0 * uniform_npoints,
+                                               pt_off ? val : val + s0 * uniform_npoints, pt_off ? pt_off + s0 : nullptr, uniform_npoints,
+                                               dst, cap, offs[k].data(), out_nbits ? out_nbits + s0 : nullptr);
+            res[k].rc = rc;
+            if (rc != GTSC_OK) res[k].err = gtsc_last_error();
+        });
+    }
+    for (std::thread& t : threads) t.join();
+    if (int rc = merge_shard_results(res)) return rc;
+    uint64_t base = 0;
+    out_off[0] = 0;
+    bool overflow = false;
+    for (int k = 0; k < nctx; k++) {
+        const uint64_t s0 = b[k], ns = b[k + 1] - b[k], total = offs[k][ns];
+        if (base + total > out_capacity_words) overflow = true;
+        else if (total) std::memmove(out_words + base, in_place ? out_words + worst[k] : priv[k].data(), total * sizeof(uint64_t));
+        for (uint64_t i = 1; i <= ns; i++) out_off[s0 + i] = base + offs[k][i];
+        base += total;
+    }
+    if (overflow) return fail(GTSC_ERR_CAPACITY, "out_words holds %llu words, the batch needs %llu",
+                              (unsigned long long)out_capacity_words, (unsigned long long)base);
+    return GTSC_OK;
+}
+
+int gtsc_decode_host_multi(int nctx, gtsc_ctx* const* ctxs, int format, uint64_t nseries, const uint64_t* words, const uint64_t* in_off,
+                           int64_t* ts, uint64_t* val, const uint64_t* pt_off, uint64_t uniform_capacity, uint64_t* out_npoints,
+                           uint32_t* status)
+{
+    if (nctx <= 0 || !ctxs) return fail(GTSC_ERR_ARG, "no contexts");
+    for (int k = 0; k < nctx; k++) if (!ctxs[k]) return fail(GTSC_ERR_ARG, "context %d is NULL", k);
+    if (nctx == 1 || nseries < (uint64_t)nctx)
+        return gtsc_decode_host(ctxs[0], format, nseries, words, in_off, ts, val, pt_off, uniform_capacity, out_npoints, status);
+    if (!words || !in_off || !out_npoints) return fail(GTSC_ERR_ARG, "words/in_off/out_npoints must not be NULL");
+    const std::vector<uint64_t> b = shard_bounds(nctx, nseries, pt_off, uniform_capacity);
+    std::vector<ShardResult> res(nctx);
+    std::vector<std::thread> threads;
+    for (int k = 0; k < nctx; k++) {
+        const uint64_t s0 = b[k], ns = b[k + 1] - b[k];
+        threads.emplace_back([=, &res] {
+            const int rc = gtsc_decode_host(ctxs[k], format, ns, words, in_off + s0, pt_off ? ts : ts + s0 * uniform_capacity,
+                                            pt_off ? val : val + s0 * uniform_capacity, pt_off ? pt_off + s0 : nullptr, uniform_capacity,
+                                            out_npoints + s0, status ? status + s0 : nullptr);
+            res[k].rc = rc;
+            if (rc != GTSC_OK) res[k].err = gtsc_last_error();
+        });
+    }
+    for (std::thread& t : threads) t.join();
+    return merge_shard_results(res);
 }
 
 }  // extern "C"

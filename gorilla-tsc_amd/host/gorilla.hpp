@@ -3,13 +3,16 @@
 // Same class and method names, argument meaning and end/error behaviour as the Java library
 // ("G/" = src/main/java/fi/iki/yak/ts/compression/gorilla/ of the reference):
 //
-//   BitOutput, BitInput      G/BitOutput.java:8-32, G/BitInput.java:8-32   the container plug-in points
+//   BitOutput                G/BitOutput.java:8-32                         the reference's interface itself: writeBit, skipBit,
+//                                                                          writeBits, flush -- any implementation receives the stream
+//   BitInput                 G/BitInput.java:8-32                          the library's two containers (a decompressor has to hand
+//                                                                          the whole image to the GPU, so it cannot pull bits one by one)
 //   LongArrayOutput          G/LongArrayOutput.java:44-56,141-145          getLongArray(), also before close()
 //   LongArrayInput           G/LongArrayInput.java:30                      wraps a long[]
 //   ByteBufferBitOutput      G/ByteBufferBitOutput.java:20-32,103          getByteBuffer()
 //   ByteBufferBitInput       G/ByteBufferBitInput.java:20-27               wraps bytes
 //   Predictor, LastValuePredictor, DifferentialFCM
-//                            G/Predictor.java:22-37, G/predictors/*.java
+//                            G/Predictor.java:22-37, G/predictors/*.java   update/predict as in the reference; the GPU runs these two
 //   GorillaCompressor        G/GorillaCompressor.java:28-37,49-71,84       (ts, out[, predictor]); addValue; close
 //   GorillaDecompressor      G/GorillaDecompressor.java:23-35,42-49        (in[, predictor]); readPair() -> null at the end
 //   Compressor/Decompressor  G/Compressor.java:24-84, G/Decompressor.java:22-42   the 1.x format
@@ -18,9 +21,13 @@
 // The codec itself runs on the GPU.  addValue() only appends to host arrays; the block is coded
 // when close() is called, and several compressors attached to one Batch are coded together in
 // a single library call by Batch::flush() (one foreign call per point would cost more than the
-// codec).  An output asked for its contents while its compressor is still open returns the
-// snapshot the reference returns there (the words written so far plus the partial word).  A
-// decompressor decodes its whole block on the first readPair().
+// codec).  The coded stream is then written into the compressor's BitOutput through the interface's own
+// methods -- writeBits(word, 64) per whole word, the rest of the bits, and flush() as the reference's close()
+// does -- so a caller's own container works as it does with the Java library.  One of the library's outputs
+// asked for its contents while its compressor is still open returns the snapshot the reference returns
+// there (the words written so far plus the partial word): the bits coded since the last time are written
+// into it first.  A decompressor decodes its whole block on the first readPair().
+// A batch of blocks spread over several GPUs: MultiBatch.
 //
 // Errors: what the Java classes throw unchecked (ArrayIndexOutOfBoundsException on a truncated
 // array, G/LongArrayInput.java:44; BufferUnderflowException, G/ByteBufferBitInput.java:87) is
@@ -78,18 +85,24 @@ private:
 };
 
 // ---------------------------------------------------------------- predictors
-// The value predictor of a 2.x compressor / decompressor.  The prediction itself happens on the
-// GPU; these objects only say which one (gtsc_set_predictor).
+// The value predictor of a 2.x compressor / decompressor: the reference's interface (G/Predictor.java:22-37).
+// The prediction itself happens on the GPU, which runs the reference's two predictors; another implementation
+// cannot be sent there, and a compressor given one throws std::invalid_argument.  update/predict of the two
+// work as in the reference for callers that use them directly.
 class Predictor {
 public:
     virtual ~Predictor() = default;
-    virtual int kind() const = 0;       // GTSC_PRED_*
-    virtual int tableSize() const { return 0; }
+    virtual void update(int64_t value) = 0;
+    virtual int64_t predict() = 0;
 };
 
 class LastValuePredictor : public Predictor {  // G/predictors/LastValuePredictor.java:10-22
 public:
-    int kind() const override { return GTSC_PRED_LAST; }
+    void update(int64_t value) override { stored_ = value; }
+    int64_t predict() override { return stored_; }
+
+private:
+    int64_t stored_ = 0;
 };
 
 class DifferentialFCM : public Predictor {  // G/predictors/DifferentialFCM.java:23-46
@@ -97,69 +110,132 @@ public:
     explicit DifferentialFCM(int size) : size_(size)
     {
         if (size <= 0) throw std::invalid_argument("Size cannot be negative and should be power of 2");
+        uint64_t n = 1;   // rounded up to a power of two, as the Java constructor does
+        while (n < (uint64_t)size) n <<= 1;
+        table_.assign(n, 0);
+        mask_ = (uint32_t)(n - 1);
     }
-    int kind() const override { return GTSC_PRED_DFCM; }
-    int tableSize() const override { return size_; }
+    void update(int64_t value) override
+    {
+        const int64_t d = (int64_t)((uint64_t)value - (uint64_t)last_value_);
+        table_[last_hash_] = d;
+        last_hash_ = ((last_hash_ << 5) ^ (uint32_t)(d >> 50)) & mask_;
+        last_value_ = value;
+    }
+    int64_t predict() override { return (int64_t)((uint64_t)table_[last_hash_] + (uint64_t)last_value_); }
+    int tableSize() const { return size_; }
 
 private:
     int size_;
+    std::vector<int64_t> table_;
+    uint32_t mask_ = 0, last_hash_ = 0;
+    int64_t last_value_ = 0;
 };
+
+// which of the GPU's predictors a Predictor object stands for
+inline void gpu_predictor_of(const Predictor& p, int& kind, int& table_size)
+{
+    if (dynamic_cast<const LastValuePredictor*>(&p)) { kind = GTSC_PRED_LAST; table_size = 0; return; }
+    if (const DifferentialFCM* d = dynamic_cast<const DifferentialFCM*>(&p)) { kind = GTSC_PRED_DFCM; table_size = d->tableSize(); return; }
+    throw std::invalid_argument("only LastValuePredictor and DifferentialFCM run on the GPU");
+}
 
 class BlockEncoder;
 
 // ---------------------------------------------------------------- outputs
-// Where a compressor's bit stream goes.  The stream arrives as a word image plus its length in
-// bits when the block is coded; the concrete classes present it as the reference's containers do.
+// Where a compressor's bit stream goes: the reference's interface, method for method (G/BitOutput.java:8-32).
+// Any implementation may be handed to a compressor; it receives the stream's bits in order (in pieces of up
+// to 64 bits) and a flush() when the block is closed.
 class BitOutput {
 public:
     virtual ~BitOutput() = default;
+    virtual void writeBit() = 0;                            // a '1' bit
+    virtual void skipBit() = 0;                             // a '0' bit
+    virtual void writeBits(int64_t value, int bits) = 0;    // the low `bits` bits of value, most significant first
+    virtual void flush() = 0;
+};
 
+// The library's own outputs also know the compressor that writes into them, so that their contents can be
+// asked for at any time.
+class TrackedOutput : public BitOutput {
 protected:
-    // words of the stream, its length in bits, and whether the block was closed
-    const std::vector<uint64_t>& stream() const { bring_up_to_date(); return words_; }
-    uint64_t bits() const { bring_up_to_date(); return nbits_; }
-    bool closed() const { return final_; }
+    inline void bring_up_to_date() const;   // has the bits coded so far written into this output
 
 private:
     friend class BlockEncoder;
-    friend class Batch;
-    inline void bring_up_to_date() const;
-    mutable std::vector<uint64_t> words_;
-    mutable uint64_t nbits_ = 0;
-    mutable bool final_ = false;
-    BlockEncoder* writer_ = nullptr;   // the compressor writing into this output
+    BlockEncoder* writer_ = nullptr;
 };
 
-class LongArrayOutput : public BitOutput {
+class LongArrayOutput : public TrackedOutput {  // G/LongArrayOutput.java:44-145
 public:
     LongArrayOutput() = default;
     explicit LongArrayOutput(int /*initialSize*/) {}  // capacity hint of the Java class; not needed here
-    // A copy of the image, as the Java method returns it: after close() the whole block, before it
-    // the words completed so far plus the current partial word.
+    void writeBit() override { writeBits(1, 1); }
+    void skipBit() override { writeBits(0, 1); }
+    void writeBits(int64_t value, int bits) override
+    {
+        uint64_t v = bits >= 64 ? (uint64_t)value : (uint64_t)value & ((1ull << bits) - 1);
+        while (bits > 0) {
+            const int take = bits < left_ ? bits : left_;
+            const uint64_t piece = take == 64 ? v : (v >> (bits - take)) & ((1ull << take) - 1);
+            cur_ |= take == 64 ? piece : piece << (left_ - take);
+            left_ -= take;
+            bits -= take;
+            if (left_ == 0) flip();
+        }
+    }
+    void flush() override { flip(); }   // stores the current word whatever it holds (G/LongArrayOutput.java:136-139)
+    // A copy of the image, as the Java method returns it (G/LongArrayOutput.java:141-145): the words completed so
+    // far plus the current partial word -- after close() that is the whole block and a zero word.
     std::vector<int64_t> getLongArray() const
     {
-        const std::vector<uint64_t>& w = stream();
-        return std::vector<int64_t>(reinterpret_cast<const int64_t*>(w.data()), reinterpret_cast<const int64_t*>(w.data()) + w.size());
+        bring_up_to_date();
+        std::vector<int64_t> a(done_.begin(), done_.end());
+        a.push_back((int64_t)cur_);
+        return a;
     }
+
+private:
+    void flip() { done_.push_back((int64_t)cur_); cur_ = 0; left_ = 64; }
+    std::vector<int64_t> done_;
+    uint64_t cur_ = 0;
+    int left_ = 64;
 };
 
-class ByteBufferBitOutput : public BitOutput {
+class ByteBufferBitOutput : public TrackedOutput {  // G/ByteBufferBitOutput.java:20-106
 public:
     ByteBufferBitOutput() = default;
     explicit ByteBufferBitOutput(int /*initialSize*/) {}
-    // The bytes between 0 and the buffer's position: floor(N/8)+1 once the block is closed (flush()
-    // stores the partial byte), floor(N/8) while it is open.  Byte i holds stream bits 8i..8i+7.
+    void writeBit() override { writeBits(1, 1); }
+    void skipBit() override { writeBits(0, 1); }
+    // (every write is masked to its width: the Java class's unmasked short write, G/ByteBufferBitOutput.java:79-83,
+    // which damages its own 1.x streams, is not reproduced)
+    void writeBits(int64_t value, int bits) override
+    {
+        for (int i = bits - 1; i >= 0; i--) {
+            cur_ = (uint8_t)(cur_ | ((((uint64_t)value >> i) & 1u) << (left_ - 1)));
+            if (--left_ == 0) flip();
+        }
+    }
+    void flush() override { flip(); }   // puts the current byte whatever it holds (G/ByteBufferBitOutput.java:93-96)
+    // The bytes between 0 and the buffer's position: floor(N/8)+1 once the block is closed, floor(N/8) while
+    // it is open (the partial byte is not in the buffer yet).  Byte i holds stream bits 8i..8i+7.
     std::vector<uint8_t> getByteBuffer() const
     {
-        const std::vector<uint64_t>& w = stream();
-        const uint64_t n = bits() / 8 + (closed() ? 1 : 0);
-        std::vector<uint8_t> b(n);
-        for (uint64_t i = 0; i < n; i++) b[i] = (i >> 3) < w.size() ? (uint8_t)(w[i >> 3] >> (56 - 8 * (i & 7))) : 0;
-        return b;
+        bring_up_to_date();
+        return done_;
     }
+
+private:
+    void flip() { done_.push_back(cur_); cur_ = 0; left_ = 8; }
+    std::vector<uint8_t> done_;
+    uint8_t cur_ = 0;
+    int left_ = 8;
 };
 
 // ---------------------------------------------------------------- inputs
+// What a decompressor reads.  The reference's BitInput is pulled bit by bit (G/BitInput.java:8-32); the GPU needs
+// the whole image at once, so the inputs here are the library's two containers, which hold it.
 class BitInput {
 public:
     virtual ~BitInput() = default;
@@ -192,13 +268,26 @@ public:
 class Batch {
 public:
     explicit Batch(Context& ctx = Context::thread_default()) : ctx_(ctx) {}
-    // Codes every closed, not yet coded block attached to this batch; their outputs are filled.
+    virtual ~Batch() = default;
+    // Codes every closed, not yet coded block attached to this batch; their outputs receive their streams.
     inline void flush();
     Context& context() const { return ctx_; }
 
+protected:
+    // One library call: images back to back in `words` (out_off[S+1]) and each stream's length in bits.
+    virtual void encode(int format, int predictor, int table_size, bool close, uint64_t S, const int64_t* block_ts, const int64_t* ts,
+                        const uint64_t* val, const uint64_t* pt_off, std::vector<uint64_t>& words, uint64_t* out_off, uint64_t* nbits)
+    {
+        if (gtsc_set_predictor(ctx_.get(), predictor, table_size) != GTSC_OK) throw std::runtime_error(gtsc_last_error());
+        const int rc = gtsc_encode_host_ex(ctx_.get(), format, close ? 0u : GTSC_ENC_NO_CLOSE, S, block_ts, ts, val, pt_off, 0, words.data(),
+                                           words.size(), out_off, nbits);
+        (void)gtsc_set_predictor(ctx_.get(), GTSC_PRED_LAST, 0);
+        if (rc != GTSC_OK) throw std::runtime_error(gtsc_last_error());
+    }
+
 private:
     friend class BlockEncoder;
-    friend class BitOutput;
+    friend class TrackedOutput;
     inline void code(const std::vector<BlockEncoder*>& blocks, bool close);
     Context& ctx_;
     std::vector<BlockEncoder*> closed_;
@@ -209,7 +298,7 @@ class BlockEncoder {
 public:
     BlockEncoder(const BlockEncoder&) = delete;
     BlockEncoder& operator=(const BlockEncoder&) = delete;
-    virtual ~BlockEncoder() { if (out_.writer_ == this) out_.writer_ = nullptr; }
+    virtual ~BlockEncoder() { if (tracked_ && tracked_->writer_ == this) tracked_->writer_ = nullptr; }
 
     void addValue(int64_t timestamp, int64_t value)
     {
@@ -239,21 +328,37 @@ public:
 
 protected:
     BlockEncoder(int format, int64_t blockTimestamp, BitOutput& out, int predictor, int table_size, Context& ctx, Batch* batch)
-        : format_(format), predictor_(predictor), table_size_(table_size), block_ts_(blockTimestamp), out_(out), ctx_(ctx), batch_(batch)
+        : format_(format), predictor_(predictor), table_size_(table_size), block_ts_(blockTimestamp), out_(out),
+          tracked_(dynamic_cast<TrackedOutput*>(&out)), ctx_(ctx), batch_(batch)
     {
-        out_.writer_ = this;
-        out_.final_ = false;
+        if (tracked_) tracked_->writer_ = this;
     }
 
 private:
     friend class Batch;
-    friend class BitOutput;
+    friend class TrackedOutput;
+    // Writes stream bits [written_, nbits) of the image into the output through the reference's interface, whole
+    // words where it can; `final`: the block is closed -- flush() follows, as in the reference's close()
+    // (G/GorillaCompressor.java:84-89).
+    void deliver(const uint64_t* words, uint64_t nbits, bool final)
+    {
+        while (written_ < nbits) {
+            const uint64_t w = words[written_ >> 6];
+            const int at = (int)(written_ & 63), room = 64 - at;
+            const int n = nbits - written_ < (uint64_t)room ? (int)(nbits - written_) : room;   // bits at..at+n-1 of this word
+            out_.writeBits((int64_t)(n == 64 ? w : (w >> (room - n)) & ((1ull << n) - 1)), n);
+            written_ += (uint64_t)n;
+        }
+        if (final) out_.flush();
+    }
     int format_, predictor_, table_size_;
     int64_t block_ts_;
     BitOutput& out_;
+    TrackedOutput* tracked_;   // the output again, when it is one of the library's
     Context& ctx_;
     Batch* batch_;
     bool closed_ = false, coded_ = false;
+    uint64_t written_ = 0;     // bits of the stream the output has received
     std::vector<int64_t> ts_;
     std::vector<uint64_t> val_;
 };
@@ -264,12 +369,16 @@ public:
     GorillaCompressor(int64_t timestamp, BitOutput& output, Context& ctx = Context::thread_default())
         : BlockEncoder(GTSC_FMT_V2, timestamp, output, GTSC_PRED_LAST, 0, ctx, nullptr) {}
     GorillaCompressor(int64_t timestamp, BitOutput& output, const Predictor& predictor, Context& ctx = Context::thread_default())
-        : BlockEncoder(GTSC_FMT_V2, timestamp, output, predictor.kind(), predictor.tableSize(), ctx, nullptr) {}
+        : BlockEncoder(GTSC_FMT_V2, timestamp, output, kind_of(predictor), size_of(predictor), ctx, nullptr) {}
     GorillaCompressor(int64_t timestamp, BitOutput& output, Batch& batch)
         : BlockEncoder(GTSC_FMT_V2, timestamp, output, GTSC_PRED_LAST, 0, batch.context(), &batch) {}
     GorillaCompressor(int64_t timestamp, BitOutput& output, const Predictor& predictor, Batch& batch)
-        : BlockEncoder(GTSC_FMT_V2, timestamp, output, predictor.kind(), predictor.tableSize(), batch.context(), &batch) {}
+        : BlockEncoder(GTSC_FMT_V2, timestamp, output, kind_of(predictor), size_of(predictor), batch.context(), &batch) {}
     static int32_t encodeZigZag32(int32_t n) { return (int32_t)(((uint32_t)n << 1) ^ (uint32_t)(n >> 31)); }
+
+private:
+    static int kind_of(const Predictor& p) { int k, n; gpu_predictor_of(p, k, n); return k; }
+    static int size_of(const Predictor& p) { int k, n; gpu_predictor_of(p, k, n); return n; }
 };
 
 class Compressor : public BlockEncoder {
@@ -300,16 +409,10 @@ inline void Batch::code(const std::vector<BlockEncoder*>& blocks, bool close)
     }
     std::vector<uint64_t> words(cap);
     const BlockEncoder& first = *blocks[0];
-    if (gtsc_set_predictor(ctx_.get(), first.predictor_, first.table_size_) != GTSC_OK) throw std::runtime_error(gtsc_last_error());
-    const int rc = gtsc_encode_host_ex(ctx_.get(), first.format_, close ? 0u : GTSC_ENC_NO_CLOSE, S, block_ts.data(), ts.data(),
-                                       val.data(), pt_off.data(), 0, words.data(), cap, out_off.data(), nbits.data());
-    (void)gtsc_set_predictor(ctx_.get(), GTSC_PRED_LAST, 0);
-    if (rc != GTSC_OK) throw std::runtime_error(gtsc_last_error());
+    encode(first.format_, first.predictor_, first.table_size_, close, S, block_ts.data(), ts.data(), val.data(), pt_off.data(), words,
+           out_off.data(), nbits.data());
     for (uint64_t s = 0; s < S; s++) {
-        BitOutput& o = blocks[s]->out_;
-        o.words_.assign(words.begin() + out_off[s], words.begin() + out_off[s + 1]);
-        o.nbits_ = nbits[s];
-        o.final_ = close;
+        blocks[s]->deliver(words.data() + out_off[s], nbits[s], close);
         if (close) {
             blocks[s]->coded_ = true;
             blocks[s]->ts_.clear();
@@ -331,9 +434,10 @@ inline void Batch::flush()
     }
 }
 
-// An output read while its compressor has not been coded yet: an open block gives its snapshot
-// (T/EncodeGorillaTest.java:483-500), a closed block waiting in a Batch makes the batch flush.
-inline void BitOutput::bring_up_to_date() const
+// One of the library's outputs read while its compressor has not been coded yet: an open block is coded as far
+// as it goes and the bits not yet delivered are written (the snapshot of T/EncodeGorillaTest.java:483-500); a
+// closed block waiting in a Batch makes the batch flush.
+inline void TrackedOutput::bring_up_to_date() const
 {
     BlockEncoder* w = writer_;
     if (!w || w->coded_) return;
@@ -344,6 +448,33 @@ inline void BitOutput::bring_up_to_date() const
     Batch one(w->ctx_);
     one.code({w}, false);
 }
+
+// A batch whose blocks are spread over several GPUs.  Blocks are independent (one compressor instance per block,
+// no shared state: G/GorillaCompressor.java:13-26), so the batch is cut into contiguous runs of blocks with about
+// equal numbers of points, one run per context, each coded by a host thread of its own through its context's
+// pipeline; the images come back in the order of the blocks.  Contexts may sit on different devices or share one.
+class MultiBatch : public Batch {
+public:
+    explicit MultiBatch(const std::vector<Context*>& contexts) : Batch(*contexts.at(0))
+    {
+        for (Context* c : contexts) shards_.push_back(c->get());
+    }
+
+protected:
+    void encode(int format, int predictor, int table_size, bool close, uint64_t S, const int64_t* block_ts, const int64_t* ts,
+                const uint64_t* val, const uint64_t* pt_off, std::vector<uint64_t>& words, uint64_t* out_off, uint64_t* nbits) override
+    {
+        for (gtsc_ctx* c : shards_)
+            if (gtsc_set_predictor(c, predictor, table_size) != GTSC_OK) throw std::runtime_error(gtsc_last_error());
+        const int rc = gtsc_encode_host_multi((int)shards_.size(), shards_.data(), format, close ? 0u : GTSC_ENC_NO_CLOSE, S, block_ts, ts, val,
+                                              pt_off, 0, words.data(), words.size(), out_off, nbits);
+        for (gtsc_ctx* c : shards_) (void)gtsc_set_predictor(c, GTSC_PRED_LAST, 0);
+        if (rc != GTSC_OK) throw std::runtime_error(gtsc_last_error());
+    }
+
+private:
+    std::vector<gtsc_ctx*> shards_;
+};
 
 // ---------------------------------------------------------------- decompressors
 // Common part of GorillaDecompressor (2.x) and Decompressor (1.x).
@@ -407,8 +538,12 @@ public:
     explicit GorillaDecompressor(const BitInput& input, Context& ctx = Context::thread_default())
         : BlockDecoder(GTSC_FMT_V2, input, GTSC_PRED_LAST, 0, ctx) {}
     GorillaDecompressor(const BitInput& input, const Predictor& predictor, Context& ctx = Context::thread_default())
-        : BlockDecoder(GTSC_FMT_V2, input, predictor.kind(), predictor.tableSize(), ctx) {}
+        : BlockDecoder(GTSC_FMT_V2, input, kind_of(predictor), size_of(predictor), ctx) {}
     static int32_t decodeZigZag32(int32_t n) { return (int32_t)(((uint32_t)n >> 1) ^ (uint32_t)(-(n & 1))); }
+
+private:
+    static int kind_of(const Predictor& p) { int k, n; gpu_predictor_of(p, k, n); return k; }
+    static int size_of(const Predictor& p) { int k, n; gpu_predictor_of(p, k, n); return n; }
 };
 
 class Decompressor : public BlockDecoder {

@@ -4,6 +4,7 @@
 //
 //   mirror_test <in.txt> <out.txt>
 //   mirror_test shapes <outdir>     the shapes of three of the reference's tests (see shapes())
+//   mirror_test plug <in.txt> <out.txt>   the same input through a caller's own BitOutput and over two contexts (see plug())
 // in.txt : "<nseries>" then per series "<format> <block_ts> <npoints>" and npoints lines
 //          "<ts> <value bits as hex>"
 // out.txt: per series "<nwords>" + words (hex), then "<npairs>" + pairs "<ts> <hex>"
@@ -95,8 +96,97 @@ static int shapes(const std::string& dir)
     return 0;
 }
 
+// A container of the caller's own: it implements the reference's BitOutput interface (G/BitOutput.java:8-32) and
+// simply records what it is told, one character per bit, 'F' per flush() -- what a user's container (or the
+// reference jar's own LongArrayOutput) would see.
+class RecordingBitOutput : public gorilla::BitOutput {
+public:
+    void writeBit() override { log += '1'; calls++; }
+    void skipBit() override { log += '0'; calls++; }
+    void writeBits(int64_t value, int bits) override
+    {
+        if (bits < 1 || bits > 64) throw std::logic_error("writeBits: bit count out of range");
+        for (int i = bits - 1; i >= 0; i--) log += (char)('0' + (((uint64_t)value >> i) & 1u));
+        calls++;
+    }
+    void flush() override { log += 'F'; calls++; }
+    std::string log;
+    size_t calls = 0;
+};
+
+// A predictor of the caller's own: the GPU cannot run it, and a compressor says so.
+class MeanPredictor : public gorilla::Predictor {
+public:
+    void update(int64_t value) override { sum += value; n++; }
+    int64_t predict() override { return n ? sum / n : 0; }
+    int64_t sum = 0, n = 0;
+};
+
+// The series of in.txt (a) each through a RecordingBitOutput, including a look at an open block's stream half way
+// (the recorder then holds a prefix of the final stream), and (b) all together through a MultiBatch over two contexts
+// on the current device, standing in for two GPUs.  out.txt: per series the recorded characters, then per series the
+// word image from the MultiBatch.
+static int plug(const char* in_path, const char* out_path)
+{
+    FILE* in = std::fopen(in_path, "r");
+    FILE* out = std::fopen(out_path, "w");
+    if (!in || !out) { std::perror("open"); return 2; }
+    size_t S;
+    if (std::fscanf(in, "%zu", &S) != 1) return 2;
+    gorilla::Context c0, c1;
+    gorilla::MultiBatch multi({&c0, &c1});
+    std::vector<std::unique_ptr<gorilla::LongArrayOutput>> outs;
+    std::vector<std::unique_ptr<gorilla::BlockEncoder>> encs;
+    for (size_t s = 0; s < S; s++) {
+        int fmt; int64_t block; size_t P;
+        if (std::fscanf(in, "%d %" SCNd64 " %zu", &fmt, &block, &P) != 3) return 2;
+        RecordingBitOutput rec;
+        std::unique_ptr<gorilla::BlockEncoder> enc;
+        if (fmt == GTSC_FMT_V2) enc.reset(new gorilla::GorillaCompressor(block, rec));
+        else                    enc.reset(new gorilla::Compressor(block, rec));
+        outs.emplace_back(new gorilla::LongArrayOutput());
+        if (fmt == GTSC_FMT_V2) encs.emplace_back(new gorilla::GorillaCompressor(block, *outs.back(), multi));
+        else                    encs.emplace_back(new gorilla::Compressor(block, *outs.back(), multi));
+        for (size_t i = 0; i < P; i++) {
+            int64_t t; uint64_t v;
+            if (std::fscanf(in, "%" SCNd64 " %" SCNx64, &t, &v) != 2) return 2;
+            enc->addValue(t, (int64_t)v);
+            encs.back()->addValue(t, (int64_t)v);
+        }
+        enc->close();
+        encs.back()->close();
+        if (rec.log.empty() || rec.log.back() != 'F') throw std::runtime_error("no flush() at close()");
+        std::fprintf(out, "%s\n", rec.log.c_str());
+    }
+    multi.flush();
+    for (size_t s = 0; s < S; s++) {
+        const std::vector<int64_t> w = outs[s]->getLongArray();
+        std::fprintf(out, "%zu", w.size());
+        for (int64_t x : w) std::fprintf(out, " %016" PRIx64, (uint64_t)x);
+        std::fprintf(out, "\n");
+    }
+    bool rejected = false;
+    try {
+        MeanPredictor mp;
+        gorilla::LongArrayOutput o;
+        gorilla::GorillaCompressor c(1500400800000LL, o, mp);
+    } catch (const std::invalid_argument&) { rejected = true; }
+    // the library's two predictors answer update/predict as the reference's do
+    gorilla::DifferentialFCM d(8);
+    for (int64_t v : {0, 10, 20, 30}) d.update(v);
+    gorilla::LastValuePredictor l;
+    l.update(7);
+    std::fprintf(out, "predictors %d %" PRId64 " %" PRId64 "\n", (int)rejected, d.predict(), l.predict());
+    std::fclose(out);
+    std::fclose(in);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "plug") {
+        try { return plug(argv[2], argv[3]); } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc == 3 && std::string(argv[1]) == "shapes") {
         try { return shapes(argv[2]); } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }

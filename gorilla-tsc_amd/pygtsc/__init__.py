@@ -23,7 +23,8 @@ SYMBOLS = (
     "gtsc_sync", "gtsc_encode_device", "gtsc_decode_device", "gtsc_compact_device", "gtsc_encode_host",
     "gtsc_decode_host", "gtsc_host_alloc", "gtsc_host_free", "gtsc_encode_device_ex", "gtsc_words_to_bytes_device",
     "gtsc_bytes_to_words_device", "gtsc_set_predictor", "gtsc_encode_host_ex", "gtsc_compact_device_noalloc", "gtsc_set_decode_ring",
-    "gtsc_set_tunable", "gtsc_get_tunable", "gtsc_last_dispatch", "gtsc_host_pipeline_idle",
+    "gtsc_set_tunable", "gtsc_get_tunable", "gtsc_last_dispatch", "gtsc_host_pipeline_idle", "gtsc_encode_host_multi",
+    "gtsc_decode_host_multi",
 )
 # gtsc_set_tunable ids and gtsc_last_dispatch bits (include/gtsc.h)
 (TUNE_LONG_POINTS, TUNE_VLONG_POINTS, TUNE_WAVE_DECODE_MAX, TUNE_WAVE_DECODE_MAX_DENSE, TUNE_WG_DECODE_MAX, TUNE_WG_DECODE_VLONG_MAX,
@@ -106,6 +107,10 @@ def lib():
     L.gtsc_encode_host_ex.argtypes = [vp, i32, C.c_uint32, u64, vp, vp, vp, vp, u64, vp, u64, vp, vp]
     L.gtsc_decode_host.restype = i32
     L.gtsc_decode_host.argtypes = [vp, i32, u64, vp, vp, vp, vp, vp, u64, vp, vp]
+    L.gtsc_encode_host_multi.restype = i32
+    L.gtsc_encode_host_multi.argtypes = [i32, C.POINTER(vp), i32, C.c_uint32, u64, vp, vp, vp, vp, u64, vp, u64, vp, vp]
+    L.gtsc_decode_host_multi.restype = i32
+    L.gtsc_decode_host_multi.argtypes = [i32, C.POINTER(vp), i32, u64, vp, vp, vp, vp, vp, u64, vp, vp]
     L.gtsc_host_alloc.restype = vp
     L.gtsc_host_alloc.argtypes = [C.c_size_t]
     L.gtsc_host_free.argtypes = [vp]
@@ -132,6 +137,50 @@ def _dp(t):
 
 def _hp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def encode_host_multi(ctxs, block_ts, ts, val, pt_off=None, uniform_npoints=0, fmt=FMT_V2, options=0):
+    """gtsc_encode_host_multi over the given Contexts: returns (words, off, nbits)."""
+    block_ts = np.ascontiguousarray(block_ts, dtype=np.int64)
+    ts = np.ascontiguousarray(ts, dtype=np.int64)
+    val = np.ascontiguousarray(val, dtype=np.uint64)
+    S = len(block_ts)
+    if pt_off is not None:
+        pt_off = np.ascontiguousarray(pt_off, dtype=np.uint64)
+        lens = np.diff(pt_off.astype(np.int64))
+    else:
+        lens = np.full(S, int(uniform_npoints), dtype=np.int64)
+    bits = 64 + np.where(lens > 0, 91 + 114 * (lens - 1), 0) + 37
+    cap = int((bits // 64 + 2).sum())
+    out = np.zeros(max(cap, 1), dtype=np.uint64)
+    off = np.zeros(S + 1, dtype=np.uint64)
+    nbits = np.zeros(S, dtype=np.uint64)
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().gtsc_encode_host_multi(len(ctxs), handles, fmt, int(options), S, _hp(block_ts), _hp(ts), _hp(val), _hp(pt_off),
+                                        int(uniform_npoints), _hp(out), cap, _hp(off), _hp(nbits)))
+    return out[: int(off[-1])], off, nbits
+
+
+def decode_host_multi(ctxs, words, in_off, pt_off=None, uniform_capacity=0, fmt=FMT_V2, check=True):
+    """gtsc_decode_host_multi over the given Contexts: returns (ts, val, npoints, status)."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    S = len(in_off) - 1
+    if pt_off is not None:
+        pt_off = np.ascontiguousarray(pt_off, dtype=np.uint64)
+        total = int(pt_off[-1])
+    else:
+        total = S * int(uniform_capacity)
+    ts = np.zeros(total, dtype=np.int64)
+    val = np.zeros(total, dtype=np.uint64)
+    npts = np.zeros(S, dtype=np.uint64)
+    st = np.zeros(S, dtype=np.uint32)
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    rc = lib().gtsc_decode_host_multi(len(ctxs), handles, fmt, S, _hp(words), _hp(in_off), _hp(ts), _hp(val), _hp(pt_off),
+                                      int(uniform_capacity), _hp(npts), _hp(st))
+    if check:
+        _check(rc)
+    return ts, val, npts, st
 
 
 class Context:

@@ -339,6 +339,27 @@ int gtsc_decode_host(gtsc_ctx *ctx, int format, uint64_t nseries,
                      const uint64_t *pt_off, uint64_t uniform_capacity,
                      uint64_t *out_npoints, uint32_t *status);
 
+/*
+ * The host-memory forms over several contexts -- normally one per GPU of the node.  Blocks are independent (one
+ * compressor instance per block, no shared state: G/GorillaCompressor.java:13-26), so the batch is cut into nctx
+ * contiguous runs of series with about equal numbers of points; run k goes through ctxs[k]'s pipeline on a host
+ * thread of its own, and the results are exactly those of the single-context call: images back to back in series
+ * order, out_off[S+1], decoded points in their slots.  No data moves between GPUs.  The contexts may sit on
+ * different devices or share one; each must be used by this call only while it runs.  Predictors and tunables are
+ * those of each context.  nctx == 1 is the single-context call.
+ */
+int gtsc_encode_host_multi(int nctx, gtsc_ctx *const *ctxs, int format, uint32_t options, uint64_t nseries,
+                           const int64_t *block_ts,
+                           const int64_t *ts, const uint64_t *val,
+                           const uint64_t *pt_off, uint64_t uniform_npoints,
+                           uint64_t *out_words, uint64_t out_capacity_words,
+                           uint64_t *out_off, uint64_t *out_nbits);
+int gtsc_decode_host_multi(int nctx, gtsc_ctx *const *ctxs, int format, uint64_t nseries,
+                           const uint64_t *words, const uint64_t *in_off,
+                           int64_t *ts, uint64_t *val,
+                           const uint64_t *pt_off, uint64_t uniform_capacity,
+                           uint64_t *out_npoints, uint32_t *status);
+
 /* Diagnostic: 1 when none of the streams of the host entry points has work in flight, 0 when one has,
  * negative on error.  (After any host entry point has returned it is 1.)  No reference counterpart. */
 int gtsc_host_pipeline_idle(gtsc_ctx *ctx);

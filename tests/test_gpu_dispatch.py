@@ -222,3 +222,35 @@ def test_host_entry_points_leave_nothing_in_flight_after_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_chunks_worker.py"), "fail"],
                        env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0 and "failure ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_one_batch_over_two_contexts():
+    """gtsc_encode_host_multi / gtsc_decode_host_multi with two contexts on device 0 standing in for two devices
+    (this box has one GPU): words, offsets, bit lengths and decoded points equal the single-context call's and the
+    oracle's, for a ragged batch of skewed lengths and for a uniform one, both formats."""
+    a, b2 = G.Context(0), G.Context(0)
+    try:
+        sk = synth.skewed(total_points=300000, seed=17, pmin=10, pmax=40000)
+        un = synth.gauge_integer(S=5001, P=120, seed=18)
+        for gfmt, ofmt in FMTS:
+            for b, uniform in ((sk, False), (un, True)):
+                kw = dict(uniform_npoints=120) if uniform else dict(pt_off=b.pt_off)
+                words, off, nbits = G.encode_host_multi([a, b2], b.block_ts, b.ts, b.val, fmt=gfmt, **kw)
+                w1, o1, n1 = a.encode_host(b.block_ts, b.ts, b.val, fmt=gfmt, want_nbits=True, **kw)
+                assert np.array_equal(off, o1) and np.array_equal(nbits, n1) and np.array_equal(words, w1)
+                ref_out, ref_off, ref_nw, _ = O.encode_batch(b.block_ts, b.ts, b.val, b.pt_off, fmt=ofmt, nthreads=8)
+                ref = np.concatenate([ref_out[int(ref_off[s]):int(ref_off[s]) + int(ref_nw[s])] for s in range(b.nseries)])
+                assert np.array_equal(words, ref), "compressed words differ from the oracle's"
+                kd = dict(uniform_capacity=120) if uniform else dict(pt_off=b.pt_off)
+                ts, val, npts, st = G.decode_host_multi([a, b2], words, off, fmt=gfmt, **kd)
+                assert not st.any() and np.array_equal(ts, b.ts) and np.array_equal(val, b.val)
+                assert np.array_equal(npts.astype(np.int64), np.diff(b.pt_off.astype(np.int64)))
+        # a damaged image in the second shard: its status and the call's return code come through
+        bad = words.copy()
+        bad[int(off[-2]) + 1:] = 0
+        ts, val, npts, st = G.decode_host_multi([a, b2], bad, off, uniform_capacity=120, fmt=FMTS[-1][0], check=False)
+        rts, rval, rnp, rst = O.decode_batch(bad, off, None, un.pt_off, fmt=FMTS[-1][1])
+        assert np.array_equal(st, rst) and np.array_equal(npts, rnp)
+    finally:
+        a.close()
+        b2.close()

@@ -97,3 +97,44 @@ def test_mirror_reference_test_shapes(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "dfcm_words.bin", dtype=np.uint64), ref)
     rts, rval, rc = O.decode_block(ref, O.V2, dfcm_size=1024)
     assert rc == O.END and np.array_equal(np.fromfile(tmp_path / "dfcm_values.bin", dtype=np.uint64), rval)
+
+
+@pytest.mark.gpu
+def test_mirror_serves_a_callers_own_bit_output_and_two_contexts(tmp_path):
+    """A hand-written implementation of the reference's BitOutput interface (G/BitOutput.java:8-32) that records
+    its calls receives exactly the oracle's bit stream followed by flush(); the same blocks through a MultiBatch
+    over two contexts give the oracle's word images; a predictor the GPU cannot run is refused."""
+    series = []
+    b = synth.ragged_mix(seed=11, nseries=60, pmax=300)
+    for s in range(b.nseries):
+        t, v = b.series(s)
+        series.append((O.V2 if s % 2 else O.V1, int(b.block_ts[s]), t, v))
+    big = synth.skewed(total_points=60000, seed=4, pmin=100, pmax=20000)
+    for s in range(big.nseries):
+        t, v = big.series(s)
+        series.append((O.V2, int(big.block_ts[s]), t, v))
+    inp, outp = tmp_path / "in.txt", tmp_path / "out.txt"
+    with open(inp, "w") as f:
+        f.write("%d\n" % len(series))
+        for fmt, block, ts, val in series:
+            f.write("%d %d %d\n" % (fmt, block, len(ts)))
+            for t, v in zip(ts.tolist(), val.tolist()):
+                f.write("%d %x\n" % (t, v))
+    r = subprocess.run([BIN, "plug", str(inp), str(outp)], capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr
+    lines = open(outp).read().split("\n")
+    S = len(series)
+    for k, (fmt, block, ts, val) in enumerate(series):
+        ref = O.encode_block(block, ts, val, fmt)
+        e = O.Encoder(block, fmt)
+        for t, v in zip(ts.tolist(), val.tolist()):
+            e.add(t, v)
+        e.close()
+        nbits = int(e.nbits)
+        want = "".join(format(int(w), "064b") for w in ref)[:nbits] + "F"
+        assert lines[k] == want, "recorded stream of series %d differs from the oracle's" % k
+        got = lines[S + k].split()
+        assert int(got[0]) == len(ref) and [int(x, 16) for x in got[1:]] == [int(w) for w in ref], "MultiBatch image %d" % k
+    tail = lines[2 * S].split()
+    # DifferentialFCM(8) after 0,10,20,30 predicts last + table[hash]; LastValuePredictor the last value
+    assert tail[0] == "predictors" and tail[1] == "1" and int(tail[3]) == 7
