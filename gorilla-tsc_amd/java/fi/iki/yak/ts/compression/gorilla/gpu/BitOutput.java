@@ -1,31 +1,25 @@
 package fi.iki.yak.ts.compression.gorilla.gpu;
 
 /**
- * Where a compressor's bit stream goes (the role of the reference's BitOutput interface,
- * G/BitOutput.java:8-32).  The codec runs on the GPU, so nothing is written bit by bit: the stream
- * arrives as a word image plus its length in bits when the block is coded, and the concrete classes
- * present it the way the reference's containers do.
+ * Where a compressor's bit stream goes: the reference's interface, method for method (G/BitOutput.java:8-32).
+ * Any implementation may be handed to a compressor.  The codec runs on the GPU, so the stream does not arrive
+ * call by call as the points are added: when the block is coded, its bits are written through these methods in
+ * order -- writeBits(word, 64) per whole word, the remaining bits in one more call -- and flush() follows when the
+ * block is closed, as in the reference's close() (G/GorillaCompressor.java:84-89).
+ *
+ * Deployed beside the reference jar, this interface is the one to drop: import
+ * fi.iki.yak.ts.compression.gorilla.BitOutput instead and the reference's own containers (or a caller's) are served.
  */
-public abstract class BitOutput {
-    private long[] words = new long[0];
-    private long nbits;
-    private boolean closed;
-    BlockEncoder writer;   // the compressor writing into this output
+public interface BitOutput {
+    /** Stores a set bit. */
+    void writeBit();
 
-    void set(long[] image, long bits, boolean blockClosed) {
-        words = image;
-        nbits = bits;
-        closed = blockClosed;
-    }
+    /** Stores a zero bit. */
+    void skipBit();
 
-    /** An output read while its compressor is still open gets the snapshot the reference returns there. */
-    private void bringUpToDate() {
-        if (writer != null) writer.bringOutputUpToDate();
-    }
+    /** Writes the low {@code bits} bits of {@code value}, most significant first. */
+    void writeBits(long value, int bits);
 
-    long[] stream() { bringUpToDate(); return words; }
-
-    long bits() { bringUpToDate(); return nbits; }
-
-    boolean blockClosed() { return closed; }
+    /** Flushes whatever the container holds back. */
+    void flush();
 }

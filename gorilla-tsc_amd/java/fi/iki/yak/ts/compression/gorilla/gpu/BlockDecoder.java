@@ -10,8 +10,15 @@ abstract class BlockDecoder {
     BlockDecoder(BitInput input, int format, Predictor p) {
         this.image = input.words();
         this.format = format;
-        this.predictor = p == null ? Gtsc.PRED_LAST : p.kind();
-        this.tableSize = p == null ? 0 : p.tableSize();
+        if (p == null || p instanceof fi.iki.yak.ts.compression.gorilla.gpu.predictors.LastValuePredictor) {
+            this.predictor = Gtsc.PRED_LAST;
+            this.tableSize = 0;
+        } else if (p instanceof fi.iki.yak.ts.compression.gorilla.gpu.predictors.DifferentialFCM) {
+            this.predictor = Gtsc.PRED_DFCM;
+            this.tableSize = ((fi.iki.yak.ts.compression.gorilla.gpu.predictors.DifferentialFCM) p).tableSize();
+        } else {
+            throw new IllegalArgumentException("only LastValuePredictor and DifferentialFCM run on the GPU");
+        }
     }
 
     /** The next pair, or null at the end of the block. */

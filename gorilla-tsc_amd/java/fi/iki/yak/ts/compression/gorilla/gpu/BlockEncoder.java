@@ -9,6 +9,7 @@ abstract class BlockEncoder {
     final BitOutput out;
     final int format, predictor, tableSize;
     private final GpuBatch batch;
+    private long written;   // bits of the stream the output has received
     long[] ts = new long[128], val = new long[128];
     int size;
     private boolean closed;
@@ -19,10 +20,32 @@ abstract class BlockEncoder {
         this.out = output;
         this.batch = batch;
         this.format = format;
-        this.predictor = p == null ? Gtsc.PRED_LAST : p.kind();
-        this.tableSize = p == null ? 0 : p.tableSize();
-        output.writer = this;
-        output.set(new long[0], 0, false);
+        // which of the GPU's predictors the object stands for
+        if (p == null || p instanceof fi.iki.yak.ts.compression.gorilla.gpu.predictors.LastValuePredictor) {
+            this.predictor = Gtsc.PRED_LAST;
+            this.tableSize = 0;
+        } else if (p instanceof fi.iki.yak.ts.compression.gorilla.gpu.predictors.DifferentialFCM) {
+            this.predictor = Gtsc.PRED_DFCM;
+            this.tableSize = ((fi.iki.yak.ts.compression.gorilla.gpu.predictors.DifferentialFCM) p).tableSize();
+        } else {
+            throw new IllegalArgumentException("only LastValuePredictor and DifferentialFCM run on the GPU");
+        }
+        if (output instanceof TrackedOutput) ((TrackedOutput) output).writer = this;
+    }
+
+    /**
+     * Writes stream bits [written, nbits) of the image into the output through the reference's interface, whole words
+     * where it can; {@code last}: the block is closed, flush() follows as in the reference's close().
+     */
+    void deliver(long[] image, long nbits, boolean last) {
+        while (written < nbits) {
+            long w = image[(int) (written >>> 6)];
+            int at = (int) (written & 63), room = 64 - at;
+            int n = (int) Math.min(nbits - written, room);
+            out.writeBits(n == 64 ? w : (w >>> (room - n)) & ((1L << n) - 1), n);
+            written += n;
+        }
+        if (last) out.flush();
     }
 
     public void addValue(long timestamp, long value) {
@@ -53,6 +76,6 @@ abstract class BlockEncoder {
             if (batch != null) batch.flush();
             return;
         }
-        GpuBatch.code(List.of(this), false);
+        new GpuBatch().code(List.of(this), false);
     }
 }

@@ -9,11 +9,20 @@ import static java.lang.foreign.ValueLayout.JAVA_INT;
 import static java.lang.foreign.ValueLayout.JAVA_LONG;
 
 /**
- * Collects closed blocks and codes them with one gtsc_encode_host_ex call per format and predictor.
+ * Collects closed blocks and codes them with one library call per format and predictor.
  * A foreign call per point would cost more than the codec, so addValue() only buffers; flush() does the work.
+ * A batch made with several contexts (normally one per GPU of the node, Gtsc.createContext(device)) spreads its
+ * blocks over them through gtsc_encode_host_multi: contiguous runs of blocks with about equal numbers of points,
+ * each through its context's pipeline on a host thread of its own.
  */
 public final class GpuBatch {
     private final List<BlockEncoder> closed = new ArrayList<>();
+    private final MemorySegment[] contexts;   // null: the calling thread's own context
+
+    public GpuBatch() { this.contexts = null; }
+
+    /** A batch over the given contexts (Gtsc.createContext), e.g. one per GPU. */
+    public GpuBatch(MemorySegment... contexts) { this.contexts = contexts.clone(); }
 
     void add(BlockEncoder c) { closed.add(c); }
 
@@ -31,7 +40,7 @@ public final class GpuBatch {
     }
 
     /** One library call for blocks of one format and predictor: closed blocks, or snapshots of open ones. */
-    static void code(List<BlockEncoder> blocks, boolean close) {
+    void code(List<BlockEncoder> blocks, boolean close) {
         int S = blocks.size();
         long total = 0, cap = 0;
         for (BlockEncoder c : blocks) { total += c.size; cap += Gtsc.maxWords(c.size); }
@@ -54,14 +63,19 @@ public final class GpuBatch {
                 p += c.size;
             }
             ptOff.setAtIndex(JAVA_LONG, S, p);
-            MemorySegment ctx = Gtsc.CONTEXT.get();
-            int rc = (int) Gtsc.SET_PREDICTOR.invokeExact(ctx, first.predictor, first.tableSize);
-            if (rc != Gtsc.OK) throw new IllegalStateException(Gtsc.lastError());
+            MemorySegment[] ctxs = contexts != null ? contexts : new MemorySegment[] {Gtsc.CONTEXT.get()};
+            MemorySegment handles = a.allocate(java.lang.foreign.ValueLayout.ADDRESS, ctxs.length);
+            int rc = Gtsc.OK;
+            for (int k = 0; k < ctxs.length; k++) {
+                handles.setAtIndex(java.lang.foreign.ValueLayout.ADDRESS, k, ctxs[k]);
+                rc = (int) Gtsc.SET_PREDICTOR.invokeExact(ctxs[k], first.predictor, first.tableSize);
+                if (rc != Gtsc.OK) throw new IllegalStateException(Gtsc.lastError());
+            }
             try {
-                rc = (int) Gtsc.ENCODE_HOST_EX.invokeExact(ctx, first.format, close ? 0 : Gtsc.ENC_NO_CLOSE, (long) S, blockTs, ts, val,
-                        ptOff, 0L, words, cap, outOff, nbits);
+                rc = (int) Gtsc.ENCODE_HOST_MULTI.invokeExact(ctxs.length, handles, first.format, close ? 0 : Gtsc.ENC_NO_CLOSE, (long) S,
+                        blockTs, ts, val, ptOff, 0L, words, cap, outOff, nbits);
             } finally {
-                int ignored = (int) Gtsc.SET_PREDICTOR.invokeExact(ctx, Gtsc.PRED_LAST, 0);
+                for (MemorySegment c : ctxs) { int ignored = (int) Gtsc.SET_PREDICTOR.invokeExact(c, Gtsc.PRED_LAST, 0); }
             }
             if (rc != Gtsc.OK) throw new IllegalStateException(Gtsc.lastError());
             for (int s = 0; s < S; s++) {
@@ -69,7 +83,7 @@ public final class GpuBatch {
                 long[] image = new long[(int) (e - b)];
                 MemorySegment.copy(words, JAVA_LONG, b * 8, image, 0, image.length);
                 BlockEncoder c = blocks.get(s);
-                c.out.set(image, nbits.getAtIndex(JAVA_LONG, s), close);
+                c.deliver(image, nbits.getAtIndex(JAVA_LONG, s), close);
                 if (close) c.coded = true;
             }
         } catch (RuntimeException e) {

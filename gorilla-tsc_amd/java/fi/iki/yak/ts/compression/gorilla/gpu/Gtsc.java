@@ -47,6 +47,16 @@ public final class Gtsc {
      *                         out_words, out_capacity_words, out_off, out_nbits) */
     static final MethodHandle ENCODE_HOST_EX = h("gtsc_encode_host_ex", FunctionDescriptor.of(JAVA_INT,
             ADDRESS, JAVA_INT, JAVA_INT, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS));
+    /* int gtsc_encode_host_multi(nctx, ctxs, format, options, nseries, block_ts, ts, val, pt_off, uniform_npoints,
+     *                            out_words, out_capacity_words, out_off, out_nbits) */
+    static final MethodHandle ENCODE_HOST_MULTI = h("gtsc_encode_host_multi", FunctionDescriptor.of(JAVA_INT,
+            JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS));
+    /* int gtsc_decode_host_multi(nctx, ctxs, format, nseries, words, in_off, ts, val, pt_off, uniform_capacity,
+     *                            out_npoints, status) */
+    static final MethodHandle DECODE_HOST_MULTI = h("gtsc_decode_host_multi", FunctionDescriptor.of(JAVA_INT,
+            JAVA_INT, ADDRESS, JAVA_INT, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS));
+    /* int gtsc_set_tunable(ctx, which, value) */
+    static final MethodHandle SET_TUNABLE = h("gtsc_set_tunable", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_LONG));
     /* int gtsc_set_predictor(ctx, predictor, table_size) */
     static final MethodHandle SET_PREDICTOR = h("gtsc_set_predictor", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT));
     /* int gtsc_decode_host(ctx, format, nseries, words, in_off, ts, val, pt_off, uniform_capacity,
@@ -73,11 +83,11 @@ public final class Gtsc {
         }
     }
 
-    /** One gtsc_ctx per thread, like the reference's non-thread-safe per-instance objects. */
-    static final ThreadLocal<MemorySegment> CONTEXT = ThreadLocal.withInitial(() -> {
+    /** A context on the given device (-1: the current one), e.g. one per GPU for a GpuBatch over the node. */
+    public static MemorySegment createContext(int device) {
         try (Arena a = Arena.ofConfined()) {
             MemorySegment out = a.allocate(ADDRESS);
-            int rc = (int) CREATE.invokeExact(-1, out);
+            int rc = (int) CREATE.invokeExact(device, out);
             if (rc != OK) throw new IllegalStateException(lastError());
             return out.get(ADDRESS, 0);
         } catch (RuntimeException e) {
@@ -85,5 +95,8 @@ public final class Gtsc {
         } catch (Throwable t) {
             throw new IllegalStateException(t);
         }
-    });
+    }
+
+    /** One gtsc_ctx per thread, like the reference's non-thread-safe per-instance objects. */
+    static final ThreadLocal<MemorySegment> CONTEXT = ThreadLocal.withInitial(() -> createContext(-1));
 }

@@ -1,14 +1,14 @@
 package fi.iki.yak.ts.compression.gorilla.gpu;
 
 /**
- * The value predictor of a 2.x compressor / decompressor (G/Predictor.java:22-37).  Prediction
- * happens on the GPU; an implementation only says which predictor the library is to use
- * (gtsc_set_predictor).
+ * The value predictor of a 2.x compressor / decompressor: the reference's interface (G/Predictor.java:22-37).
+ * The prediction itself happens on the GPU, which runs the reference's two predictors, LastValuePredictor and
+ * DifferentialFCM; a compressor given any other implementation throws IllegalArgumentException.
  */
 public interface Predictor {
-    /** Gtsc.PRED_LAST or Gtsc.PRED_DFCM. */
-    int kind();
+    /** Give the real value. */
+    void update(long value);
 
-    /** Table size of DifferentialFCM; ignored otherwise. */
-    default int tableSize() { return 0; }
+    /** Predicts the next value. */
+    long predict();
 }
