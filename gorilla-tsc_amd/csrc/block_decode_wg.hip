@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "codec_device.hpp"
+#include "diag.hpp"   // measurement hooks: empty in the shipped library
 #include "kernels.hpp"
 #include "wave_util.hpp"
 
@@ -117,16 +118,6 @@ __device__ __forceinline__ void wg_barrier()
     asm volatile("" ::: "memory");
 }
 
-// -DGTSC_WG_STAMP: a diagnostic build that prints where the cycles of waves 0 and 1 of a block went (never shipped)
-#ifdef GTSC_WG_STAMP
-#define GTSC_WG_STAMP_DECL uint64_t tk_other = 0, tk_x1 = 0, tk_x2 = 0, tk_b1 = 0, tk_y = 0, tk_b2 = 0, tk_z = 0, tk_prev = __builtin_amdgcn_s_memtime(); uint32_t tk_ticks = 0;
-#define GTSC_WG_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
-#define GTSC_WG_STAMP_PRINT if (lane == 0 && wave < 2) printf("wave %u: x1 %llu x2 %llu b1 %llu y %llu b2 %llu z %llu other %llu\n", wave, (unsigned long long)tk_x1, (unsigned long long)tk_x2, (unsigned long long)tk_b1, (unsigned long long)tk_y, (unsigned long long)tk_b2, (unsigned long long)tk_z, (unsigned long long)tk_other);
-#else
-#define GTSC_WG_STAMP_DECL
-#define GTSC_WG_TICK(acc_)
-#define GTSC_WG_STAMP_PRINT
-#endif
 
 __device__ __forceinline__ int32_t sext7(uint32_t x) { return (int32_t)((x & 127u) ^ 64u) - 64; }
 

@@ -12,21 +12,9 @@
 #include <mutex>
 
 #include "codec_device.hpp"
+#include "diag.hpp"   // measurement hooks: empty in the shipped library
 #include "kernels.hpp"
 #include "wave_util.hpp"
-
-// Measurement switches, never set in the shipped library:
-//   -DGTSC_STAMP        per-wave cycle stamps (s_memtime) left in the outputs, read by tools/stamps.py
-//   -DGTSC_ABLATE=n     leaves one cost out to see what it is worth (1/3: encoder arithmetic, 4: decoder
-//                       stores, 5: decoder tile writes, 6: decoder ring reads, 7: both, 8: the encoder's stores
-//                       of compressed words before the last copy); results are wrong
-//   -DGTSC_LDS_PAD=n    pads the encoder's LDS to lower its occupancy (-DGTSC_DEC_LDS_PAD=n: the decoder's)
-//   -DGTSC_POISON=x     the decoder's input rings start out filled with x (nothing may depend on slots never written)
-//   -DGTSC_RUNSTAT      one wave prints how many chunks it decoded by run skipping, in how many steps, and why not
-//   -DGTSC_PLAIN_STORES the decoder's full-chunk stores as plain instead of streaming stores
-#ifndef GTSC_ABLATE
-#define GTSC_ABLATE 0
-#endif
 
 namespace gtsc {
 
@@ -185,9 +173,7 @@ __device__ __forceinline__ uint64_t series_of_lane(uint32_t block, uint32_t lane
 // shift for a layout: uniform point counts only; phase period = 16 / gcd(points mod 16, 16) series
 static uint32_t group_shift_of(const Layout& pts)
 {
-#ifdef GTSC_STAMP
-    return 0;  // the stamps of a wave overwrite the outputs of the series after its first
-#endif
+    if (DIAG_STAMPED) return 0;  // (a stamped build: the stamps of a wave overwrite the outputs of the series after its first)
     if (pts.off) return 0;
     const uint32_t m = (uint32_t)(pts.uniform & 15);
     if (m == 0) return 0;
@@ -218,16 +204,6 @@ constexpr uint32_t MAX_ROW_POINTS = 0x7FFFFF00u;
 constexpr uint32_t RING_WORDS = 16;
 constexpr uint32_t RING_BLOCK = 8;
 constexpr uint32_t RING_TRIGGER = RING_WORDS - 4;
-
-#ifndef GTSC_LAND_LOW
-#define GTSC_LAND_LOW 5u
-#endif
-#ifndef GTSC_DEC_LDS_PAD
-#define GTSC_DEC_LDS_PAD 0
-#endif
-#ifndef GTSC_LDS_PAD
-#define GTSC_LDS_PAD 0
-#endif
 
 // ring rows are padded by one word so that the lanes' ds_write_b64 spread over the banks
 constexpr uint32_t RING_ROW_BYTES = RING_WORDS * 8 + 8;
@@ -337,7 +313,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         }                                                                                      \
         _Pragma("unroll") for (uint32_t i = 0; i < PASSES; i++) {                              \
             uint64_t* dst = a.out_words + fdst[i];                                             \
-            if (GTSC_ABLATE == 8 && !(FINAL)) {                                                \
+            if (DIAG_NO_ENC_STORES && !(FINAL)) {                                              \
                 asm volatile("" ::"v"(fx0[i]), "v"(fx1[i]), "v"(dst), "v"(fmode[i]));          \
             } else if (fmode[i] == 2) {                                                        \
                 const U4 v = {(uint32_t)fx0[i], (uint32_t)(fx0[i] >> 32), (uint32_t)fx1[i], (uint32_t)(fx1[i] >> 32)}; \
@@ -395,13 +371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         }                                                                                      \
     }
 
-#ifdef GTSC_STAMP
-    // diagnostic build only: where a wave's cycles go (never shipped; results land in the slot tail)
-    uint64_t tk_stage = 0, tk_fetch = 0, tk_comp = 0, tk_prev = __builtin_amdgcn_s_memtime();
-#define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define GTSC_TICK(acc_)
-#endif
+    GTSC_ENC_STAMPS_BEGIN
     uint32_t run_wait = 0;  // wave-uniform: chunks to code in lock step before run skipping is tried again
     uint32_t run_backoff = 4;
     wave_sync();  // rows[] visible
@@ -525,13 +495,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
                     const U4 tl = *reinterpret_cast<const U4*>(tile_ts + TT::addr(lane, q >> 1));
                     const U4 va = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q));
                     const U4 vb = *reinterpret_cast<const U4*>(tile_val + tile_addr(lane, q + 1));
-#if GTSC_ABLATE == 1 || GTSC_ABLATE == 3
-                    e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
-#else
-                    if (!idle) e.add_next2(tl.x, 0u, lo64(va), tl.y, 0u, hi64(va), sink);
-                    if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
-                    if (!idle) e.add_next2(tl.z, 0u, lo64(vb), tl.w, 0u, hi64(vb), sink);
-#endif
+                    if (DIAG_NO_ENC_ARITH) {
+                        e.acc ^= lo64(va) ^ hi64(va) ^ lo64(vb) ^ hi64(vb) ^ tl.x ^ tl.y ^ tl.z ^ tl.w;
+                    } else {
+                        if (!idle) e.add_next2(tl.x, 0u, lo64(va), tl.y, 0u, hi64(va), sink);
+                        if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
+                        if (!idle) e.add_next2(tl.z, 0u, lo64(vb), tl.w, 0u, hi64(vb), sink);
+                    }
                     if (any_lane(e.widx >= trigger)) GTSC_FLUSH(false)
                 }
             } else {
@@ -653,16 +623,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void en
         if (a.no_close) e.snapshot(sink); else e.finish(sink);
     }
     GTSC_FLUSH(true)
-#ifdef GTSC_STAMP
-    {
-        uint64_t tk_flush = 0;
-        GTSC_TICK(tk_flush)
-        if (lane == 0) {
-            uint64_t* dbg = a.out_words + a.slots.begin(s) + a.slots.size(s) - 4;
-            dbg[0] = tk_stage; dbg[1] = tk_fetch; dbg[2] = tk_comp; dbg[3] = tk_flush;
-        }
-    }
-#endif
+    GTSC_ENC_STAMPS_END(a, s, lane)
 #undef GTSC_FLUSH
     if (valid) {
         // a block beyond the tiled form's point limit was coded up to the limit: reported, not silent
@@ -733,10 +694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     DecRow* const rows = reinterpret_cast<DecRow*>(lds + OFF_ROWS);
     U4* const runs = reinterpret_cast<U4*>(lds + OFF_RUNS);  // RUN_SKIP only: {timestamp before the chunk (low half), delta, slots written, -}
 
-#ifdef GTSC_STAMP
-    const uint64_t tk_entry = __builtin_amdgcn_s_memtime();
-    uint64_t tk_p1 = 0, tk_p2 = 0;
-#endif
+    GTSC_DEC_STAMPS_ENTRY
     const uint32_t lane = threadIdx.x;
     if (a.ring_by_plan) {
         // both forms of the kernel were launched: the one that suits the batch's density works (above 40 compressed bits
@@ -746,14 +704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     }
     const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
     const bool valid = s < a.nseries && !left_to_block_kernel(a, s);
-#ifdef GTSC_STAMP
-    uint64_t tk_pk;
-    {
-        uint32_t probe = valid ? 1u : 0u;
-        asm volatile("" : "+v"(probe));
-        __builtin_amdgcn_sched_barrier(0); tk_pk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
+    GTSC_DEC_STAMP_PROBE(valid)
     // The slot bounds are known before the image length is: the first 64 bytes of the slot are
     // requested right away and the length is looked at when they have arrived (one memory
     // latency instead of two).  Ring words past the image's end are never parsed.
@@ -794,9 +745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         my_ring[sl] = x0; my_ring[sl + 1] = x1;                                                \
         if (sl == 0) { my_ring[IN_RING_WORDS] = x0; my_ring[IN_RING_WORDS + 1] = x1; }         \
     }
-#ifdef GTSC_POISON
-    for (uint32_t i = 0; i < IN_RING_WORDS + 3; i++) my_ring[i] = GTSC_POISON;  // diagnostic build: what slots never written hold
-#endif
+    GTSC_DIAG_POISON_RING(my_ring, IN_RING_WORDS + 3)
     // ---- initial fill: words 0..7 of the lane's own slot (separate variables, not an array: the
     // compiler would copy a whole array of quads, and wait for its loads, after every conditional load)
     uint64_t nw64 = ssz64;
@@ -808,16 +757,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         GTSC_RING_LOAD(q2, b2, 4u)
         GTSC_RING_LOAD(q3, b3, 6u)
         if (valid && a.in_nwords) nw64 = a.in_nwords[s];  // in flight together with the ring's words
-#ifdef GTSC_STAMP
-        __builtin_amdgcn_sched_barrier(0); tk_p1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-#endif
+        GTSC_DEC_STAMP_P1
         GTSC_RING_STORE(q0, b0, 0u)
         GTSC_RING_STORE(q1, b1, 2u)
         GTSC_RING_STORE(q2, b2, 4u)
         GTSC_RING_STORE(q3, b3, 6u)
-#ifdef GTSC_STAMP
-        __builtin_amdgcn_sched_barrier(0); tk_p2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-#endif
+        GTSC_DEC_STAMP_P2
     }
     // an image cannot be longer than its slot
     const uint32_t nw = nw64 > ssz ? ssz : (uint32_t)nw64;
@@ -891,39 +836,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     uint32_t ts_ref = 0;               // high half that this chunk's timestamps of the lane share
     uint32_t n0 = 0;                   // n when the chunk began
     uint32_t dmask = 0;                // slots of this chunk whose timestamps the lane stored itself
-#ifdef GTSC_STAMP
-    uint64_t tk_comp = 0, tk_flush = 0, tk_land = 0, tk_prev = __builtin_amdgcn_s_memtime();
-    const uint64_t tk_pro = tk_prev - tk_entry;
-#define GTSC_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
-#define GTSC_LAND_STAMP() { __builtin_amdgcn_sched_barrier(0); const uint64_t t0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tk_land += __builtin_amdgcn_s_memtime() - t0_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define GTSC_TICK(acc_)
-#define GTSC_LAND_STAMP()
-#endif
-#if GTSC_ABLATE == 5 || GTSC_ABLATE == 7
-#define GTSC_TILE_WRITE(T_, P_, X_) asm volatile("" ::"v"(X_));
-#else
-#define GTSC_TILE_WRITE(T_, P_, X_) *reinterpret_cast<T_*>(P_) = (T_)(X_);
-#endif
+    GTSC_DEC_STAMPS_BEGIN
     // The three-word window of a lane's next point is read from its ring as soon as the position is
     // known -- at the end of the point before -- so that the LDS round trip runs under the rest of
     // that point (votes, tile writes, top-up checks) instead of at the head of the next one.  A point
     // that commits wholesale has its successor's window inside the ring already (new position <
     // guard); top-ups that land in between write other slots.
-    uint64_t w0, w1, w2;
+    uint64_t w0 = my_ring[d.widx & (IN_RING_WORDS - 1)], w1 = my_ring[(d.widx & (IN_RING_WORDS - 1)) + 1],
+             w2 = my_ring[(d.widx & (IN_RING_WORDS - 1)) + 2];
 #define GTSC_WINDOW_READ()                                                                     \
     {                                                                                          \
-        const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); \
-        w0 = w[0]; w1 = w[1]; w2 = w[2];                                                       \
+        if (DIAG_NO_RING_READS) {                                                              \
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));                                   \
+        } else {                                                                               \
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(my_ring) + (d.widx & (IN_RING_WORDS - 1)); \
+            w0 = w[0]; w1 = w[1]; w2 = w[2];                                                   \
+        }                                                                                      \
     }
-    GTSC_WINDOW_READ()
-#if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
-#undef GTSC_WINDOW_READ
-#define GTSC_WINDOW_READ() asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
-#define GTSC_FORCE_FAST true
-#else
-#define GTSC_FORCE_FAST false
-#endif
 // One point of every lane.  Finished lanes ride along on the wholesale path (their rows are
 // bounded at flush time), so a ragged wave keeps using it.
 #define GTSC_POINT(KK)                                                                         \
@@ -949,7 +878,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             const uint64_t rare_m = (eos_m | (lanes(p.changed) & lanes(p.nbits == 0)) |        \
                                      lanes(t.widx >= guard) | lanes(t.stored_ts == 0) |        \
                                      lanes((uint32_t)(t.stored_ts >> 32) != ts_ref)) & active_m; \
-            if (GTSC_FORCE_FAST || rare_m == 0) {                                              \
+            if (DIAG_NO_RING_READS || rare_m == 0) {                                           \
                 d = t;                                                                         \
                 GTSC_WINDOW_READ()                                                             \
                 GTSC_TILE_WRITE(uint32_t, tile_ts + adt + (KK) * 4, d.stored_ts)               \
@@ -1083,9 +1012,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
     bool stamps_mode = false;  // wave-uniform: the run-skipping step that takes interval changes along is in use
     uint32_t calm = 0;         // chunks in a row in that form without an interval change
     if constexpr (RUN_SKIP) runs[lane] = U4{0u, 0u, 1u, 0u};  // a row without a series: never stored, but looked at
-#ifdef GTSC_RUNSTAT
-    uint32_t rs_try = 0, rs_ok = 0, rs_steps = 0, rs_chunks = 0; uint64_t rs_why = 0;
-#endif
+    GTSC_RUNSTAT_DECL
     uint32_t run_backoff = 1;  // doubles with every failed attempt
     const uint32_t swz = ((lane >> 1) & (PIECES - 1)) << 1;  // slot j of this lane's tile row sits at (j ^ swz) * 8
     uint8_t* const my_vals = tile_val + lane * ROW_BYTES;
@@ -1095,10 +1022,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         dmask = 0;
         if (dense) dense--;
         bool skipped = false;      // wave-uniform: the chunk was decoded by run skipping
-#ifdef GTSC_RUNSTAT
-        rs_chunks++;
-        if (c != 0 && run_wait == 0) rs_why |= (dense != 0 ? 1u : 0u) | (slow_m != 0 ? 2u : 0u) | (active_m != ~0ull ? 4u : 0u) | (lanes(n + DCH > cap) ? 8u : 0u) | (lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u) ? 16u : 0u);
-#endif
+        GTSC_RUNSTAT_CHUNK((c != 0 && run_wait == 0) ? ((dense != 0 ? 1u : 0u) | (slow_m != 0 ? 2u : 0u) | (active_m != ~0ull ? 4u : 0u) | (lanes(n + DCH > cap) ? 8u : 0u) | (lanes((uint32_t)((uint64_t)d.stored_delta >> 32) != 0u) ? 16u : 0u)) : 0u)
         uint32_t run_slots = 1u;   // slots of the chunk whose values the lane wrote (slot 0: the value before the chunk)
         uint32_t run_stamps = 0;   // slots of the chunk whose timestamps the lane wrote (see below)
         const uint32_t run_ts = (uint32_t)d.stored_ts, run_delta = (uint32_t)d.stored_delta;
@@ -1131,9 +1055,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                     else if (++calm >= 8) stamps_mode = false;
                 }
                 bad_m |= lanes((uint32_t)(d.stored_ts >> 32) != ts_ref) & active_m;
-#ifdef GTSC_RUNSTAT
-                rs_try++; rs_steps += steps; if (bad_m == 0) rs_ok++;
-#endif
+                GTSC_RUNSTAT_ATTEMPT(steps, bad_m == 0)
                 if (bad_m == 0) {
                     skipped = true;
                     // a chunk of ten steps or more would have been quicker in lock step (nine is where the two meet):
@@ -1199,10 +1121,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             }
         }
         }  // !skipped
-#if GTSC_ABLATE == 6 || GTSC_ABLATE == 7
-        if (active && c * DCH >= cap) { active = false; nfin = n; }
-        active_m = lanes(active);
-#endif
+        if (DIAG_NO_RING_READS) {  // (nothing tells such a build where a stream ends)
+            if (active && c * DCH >= cap) { active = false; nfin = n; }
+            active_m = lanes(active);
+        }
         GTSC_TICK(tk_comp)
         // ---- flush the chunk: what this row has to write out, in slots of this chunk
         const uint32_t nn = active ? n : nfin;
@@ -1264,17 +1186,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
                 const U4 t = {t0[i], ri[i].w, t1[i], ri[i].w};
                 const U4 v = {(uint32_t)q0[i], (uint32_t)(q0[i] >> 32), (uint32_t)q1[i], (uint32_t)(q1[i] >> 32)};
                 if (ri[i].z != DEC_ROW_FULL) continue;  // a row without a series, or one that has ended
-#if GTSC_ABLATE == 4
-                asm volatile("" ::"v"(t), "v"(v), "v"(idx));
-#else
-#ifdef GTSC_PLAIN_STORES
-                *reinterpret_cast<U4*>(a.ts + idx) = t;
-                *reinterpret_cast<U4a8*>(a.val + idx) = v;
-#else
-                __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
-                __builtin_nontemporal_store(v, reinterpret_cast<U4a8*>(a.val + idx));
-#endif
-#endif
+                GTSC_CHUNK_STORE(U4, a.ts + idx, t)
+                GTSC_CHUNK_STORE(U4a8, a.val + idx, v)
             }
         } else if (all_lanes(info == DEC_ROW_FULL)) {
             // every row has all 16 slots of this chunk: read everything, then store everything
@@ -1290,18 +1203,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
             for (uint32_t i = 0; i < PASSES; i++) {
                 const int64_t idx = (int64_t)(((uint64_t)ri[i].y << 32) | ri[i].x) + (int64_t)v0;
                 const U4 t = {qt[i].x, ri[i].w, qt[i].y, ri[i].w};
-#if GTSC_ABLATE == 4
-                asm volatile("" ::"v"(t), "v"(qv[i]), "v"(idx));
-#else
-                // whole aligned lines that nothing reads again soon: streaming stores
-#ifdef GTSC_PLAIN_STORES
-                *reinterpret_cast<U4*>(a.ts + idx) = t;
-                *reinterpret_cast<U4a8*>(a.val + idx) = qv[i];
-#else
-                __builtin_nontemporal_store(t, reinterpret_cast<U4*>(a.ts + idx));
-                __builtin_nontemporal_store(qv[i], reinterpret_cast<U4a8*>(a.val + idx));
-#endif
-#endif
+                GTSC_CHUNK_STORE(U4, a.ts + idx, t)
+                GTSC_CHUNK_STORE(U4a8, a.val + idx, qv[i])
             }
         } else {
             // ragged chunk (a block's first or last one, or directly stored timestamps): the same
@@ -1335,9 +1238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         wave_sync();
         GTSC_TICK(tk_flush)
     }
-#ifdef GTSC_RUNSTAT
-    if (blockIdx.x == 1000 && lane == 0) printf("runstat: chunks %u tried %u ok %u steps %u why %llx\n", rs_chunks, rs_try, rs_ok, rs_steps, (unsigned long long)rs_why);
-#endif
+    GTSC_RUNSTAT_PRINT(lane)
 #undef GTSC_TOPUP_LAND
 #undef GTSC_TOPUP_ISSUE
 #undef GTSC_TOPUP_NEXT
@@ -1353,10 +1254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (a.status) a.status[s] = st;
         if (st) atomicOr(a.flags, st);
     }
-#ifdef GTSC_STAMP
-    wave_sync();  // diagnostic build: the stamps replace two of the wave's counts
-    if (lane == 0) { a.out_npoints[s + 1] = tk_comp; a.out_npoints[s + 2] = tk_flush; a.out_npoints[s + 3] = tk_pro; a.out_npoints[s + 4] = tk_p1 - tk_entry; a.out_npoints[s + 5] = tk_p2 - tk_p1; a.out_npoints[s + 6] = tk_pk - tk_entry; a.out_npoints[s + 7] = tk_land; }
-#endif
+    GTSC_DEC_STAMPS_END(a, s, lane)
 }
 
 // ------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 per gtsc kernel, average duration and average counter values per launch."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -16,6 +17,26 @@ for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), re
 print("== kernel-trace stats (ns)")
 for name, calls, avg, mn, mx in rows:
     print("%-60s calls=%d avg=%.0f min=%.0f max=%.0f" % (name[:60], calls, avg, mn, mx))
+
+def bench_line(path):
+    if not os.path.exists(path):
+        return None
+    for ln in open(path):
+        if ln.startswith("{") and '"metric"' in ln:
+            return json.loads(ln)
+    return None
+
+# the bench lines of the same lease: the process under the trace and the untraced runs either side of it
+print("== bench.py's own event times in this lease (ms: mean, and min/median/max over its timed steps)")
+for label, fn in (("untraced, before", "untraced_before.log"), ("under the kernel trace", "trace.log"), ("untraced, after", "untraced_after.log")):
+    b = bench_line(os.path.join(root, fn))
+    if b is None:
+        continue
+    r = b["roofline"]
+    es, ds = r.get("encode_ms_spread", {}), r.get("decode_ms_spread", {})
+    print("%-24s compress %.4f (%s/%s/%s)  decompress %.4f (%s/%s/%s)  value %.1f %s  frac %.3f" % (
+        label, r["encode_ms"], es.get("min"), es.get("median"), es.get("max"),
+        r["decode_ms"], ds.get("min"), ds.get("median"), ds.get("max"), b["value"], b["unit"], r["frac"]))
 counters = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
@@ -37,7 +58,6 @@ for k, cs in counters.items():
         print("   written bytes (WRITE_SIZE KiB x1024):    %.4g" % (w * 1024))
 
 # HBM traffic per launch for bench.py's roofline.traffic (default workload only)
-import json
 traffic = {"workload": "gauge", "series": 1000000, "points": 120, "source": os.path.basename(root.rstrip("/"))}
 for k, cs in counters.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
