@@ -916,26 +916,28 @@ __global__ __launch_bounds__(64) void decode_block_kernel(DecodeArgs a, uint32_t
 // images are, and how dense every 64th image of the batch is.  All decompressors of the batch read it.
 __global__ __launch_bounds__(256) void plan_decode_kernel(DecodeArgs a, DecodePlan* plan)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = s < a.nseries;
-    const uint64_t cap = in ? a.pts.size(s) : 0;
-    const bool is_long = in && cap >= a.tun.long_points, is_vlong = in && cap >= a.tun.vlong_points;
-    const bool sampled = in && (s & 63u) == 0;
-    const uint64_t nw = (is_long || sampled) ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
-    const uint64_t ml = lanes(is_long), mv = lanes(is_vlong);
-    unsigned long long* const out = reinterpret_cast<unsigned long long*>(plan);
-    if (ml) {
-        const uint64_t w = wave_inclusive_scan64<false>(is_long ? nw : 0ull), c = wave_inclusive_scan64<false>(is_long ? cap : 0ull);
-        if ((threadIdx.x & 63) == 63) {
-            atomicAdd(out + 0, (unsigned long long)__builtin_popcountll(ml));
-            atomicAdd(out + 1, (unsigned long long)__builtin_popcountll(mv));
-            atomicAdd(out + 2, (unsigned long long)w);
-            atomicAdd(out + 3, (unsigned long long)c);
-        }
+    // Every thread sums over its series, a workgroup adds its threads up through LDS, and one thread adds the six
+    // sums to the plan: few atomics on the same six words however many series there are.
+    __shared__ unsigned long long part[4][6];
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.nseries; s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t cap = a.pts.size(s);
+        const bool is_long = cap >= a.tun.long_points, is_vlong = cap >= a.tun.vlong_points;
+        const bool sampled = (s & 63u) == 0;
+        const uint64_t nw = (is_long || sampled) ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
+        if (is_long) { acc[0]++; acc[2] += nw; acc[3] += cap; }
+        if (is_vlong) acc[1]++;
+        if (sampled) { acc[4] += nw; acc[5] += cap; }
     }
-    if (sampled && (nw | cap)) {   // (one lane per wave)
-        atomicAdd(out + 4, (unsigned long long)nw);
-        atomicAdd(out + 5, (unsigned long long)cap);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int i = 0; i < 6; i++) {
+        const uint64_t t = wave_inclusive_scan64<false>(acc[i]);
+        if (lane == 63) part[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const unsigned long long t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(plan) + threadIdx.x, t);
     }
 }
 
@@ -973,7 +975,8 @@ hipError_t launch_decode_plan(const DecodeArgs& a, hipStream_t stream)
     if (hipError_t e = hipMemsetAsync(a.plan_buf, 0, sizeof(DecodePlan), stream)) return e;
     if (a.nseries == 0) return hipSuccess;
     if (a.dispatch) *a.dispatch |= DISPATCH_PLAN;
-    hipLaunchKernelGGL(plan_decode_kernel, dim3((uint32_t)((a.nseries + 255) / 256)), dim3(256), 0, stream, a, a.plan_buf);
+    const uint64_t groups = (a.nseries + 255) / 256;
+    hipLaunchKernelGGL(plan_decode_kernel, dim3((uint32_t)(groups < 256 ? groups : 256)), dim3(256), 0, stream, a, a.plan_buf);
     return hipGetLastError();
 }
 
