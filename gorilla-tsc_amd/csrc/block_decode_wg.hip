@@ -47,18 +47,20 @@ constexpr uint32_t QCAP = RPOS / 2;        // a region holds at most that many p
 constexpr uint32_t MAXB = QCAP / 64;       // batches of 64 queued points per region
 
 // What a point starting at a bit position looks like ("hop word"):
-//   bits 0..7    how far the chain hops from here: the point's length without the payload of a reused window
+//   bits 0..8    where the chain lands from here, counted from the start of the position's row of 64: the
+//                position's place in the row plus the point's length without the payload of a reused window
 //                ('10' codes: + window bits) -- or, where a run of '00' points (regular interval, unchanged
-//                value) begins, the bits of the whole run as far as it stays inside the position's row of 64
+//                value) begins, plus the bits of the whole run as far as it stays inside the row
 //   bit 9        such a run;  bit 10 / 11: the value code is '10' / '11';  bit 12: the position holds the end marker
 //   bits 13..19  significant bits, bits 20..26 trailing zeros (7 bits, signed) of a '11' code's window
-constexpr uint32_t HW_RUN = 0x200u, HW_T1 = 0x400u, HW_T2 = 0x800u, HW_EOS = 0x1000u;
-constexpr uint32_t HW_HOP = 0x1EFFu;   // the hop and its flags
+//   bit 31       a run, a '11' code or an end marker: not a plain hop
+constexpr uint32_t HW_RUN = 0x200u, HW_T1 = 0x400u, HW_T2 = 0x800u, HW_EOS = 0x1000u, HW_SPECIAL = 0x80000000u;
+constexpr uint32_t HW_NEXT = 0x1FFu;
 __device__ __forceinline__ uint32_t hw_sig(uint32_t hw) { return (hw >> 13) & 127u; }
 __device__ __forceinline__ uint32_t hw_tr7(uint32_t hw) { return (hw >> 20) & 127u; }
-// the length of the point itself (a position inside a run holds a '00' point)
-__device__ __forceinline__ uint32_t hw_fixed(uint32_t hw) { return (hw & HW_RUN) ? 2u : (hw & 255u); }
-__device__ __forceinline__ uint32_t hw_zpc(uint32_t hw) { return (hw & HW_RUN) ? (hw & 255u) >> 1 : 0u; }
+// the length of the point itself at place `at` of its row (a position inside a run holds a '00' point)
+__device__ __forceinline__ uint32_t hw_fixed(uint32_t hw, uint32_t at) { return (hw & HW_RUN) ? 2u : (hw & HW_NEXT) - at; }
+__device__ __forceinline__ uint32_t hw_zpc(uint32_t hw, uint32_t at) { return (hw & HW_RUN) ? ((hw & HW_NEXT) - at) >> 1 : 0u; }
 
 // `at`: the position's place in its row of 64 (a run is cut where the row ends)
 template <int FMT>
@@ -88,7 +90,8 @@ __device__ __forceinline__ uint32_t classify_position(uint64_t hi, uint32_t at)
     const uint32_t zbits = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
     const uint32_t room = 64u - at;
     const uint32_t zp = (zbits < room ? zbits : room) >> 1;
-    return (zp ? (2u * zp) | HW_RUN : fixed) | (t1 ? HW_T1 : 0u) | (t2 ? HW_T2 : 0u) | (eos ? HW_EOS : 0u) | (sig << 13) | (trail << 20);
+    return (at + (zp ? 2u * zp : fixed)) | (zp ? HW_RUN : 0u) | (t1 ? HW_T1 : 0u) | (t2 ? HW_T2 : 0u) | (eos ? HW_EOS : 0u) | (sig << 13) |
+           (trail << 20) | ((zp || t2 || eos) ? HW_SPECIAL : 0u);
 }
 
 struct WgLds {
@@ -131,6 +134,7 @@ struct Walk {
     uint32_t cool;           // rows to pass before strides are tried again
     uint32_t found_total;    // points found so far, the block's first one included
     bool stop, clean_end;
+    GTSC_WG_WALK_DECL
 };
 
 // Follows the chain of point starts through region k (positions [k RPOS, (k+1) RPOS)) from w.cur on and
@@ -150,7 +154,7 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
             const uint64_t cand = w.cur + (uint64_t)lane * s;
             const bool inreg = cand < rend;
             const uint32_t hw = inreg ? L.hopw[(uint32_t)cand & (2 * RPOS - 1)] : (HW_EOS | 0u);
-            const uint32_t len = hw_fixed(hw) + ((hw >> 10) & 1u) * w.wnb;
+            const uint32_t len = hw_fixed(hw, (uint32_t)cand & 63u) + ((hw >> 10) & 1u) * w.wnb;
             const bool ok = inreg && (hw & (HW_T2 | HW_EOS)) == 0 && len == s && cand + len < limit && w.found_total + lane < cap;
             const uint64_t bad = lanes(!ok);
             const uint32_t js = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
@@ -170,8 +174,8 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
         uint32_t p = (uint32_t)w.cur & 63u;
         const uint32_t hw = L.hopw[((uint32_t)row & (2 * RPOS - 1)) + lane];
         const uint32_t t1 = (hw >> 10) & 1u;
-        uint32_t len = hw_fixed(hw) + t1 * w.wnb;
-        const uint32_t zpc = hw_zpc(hw);                  // '00' points from here on, inside the row
+        uint32_t len = hw_fixed(hw, lane) + t1 * w.wnb;
+        const uint32_t zpc = hw_zpc(hw, lane);            // '00' points from here on, inside the row
         const uint32_t sig = hw_sig(hw), tr7 = hw_tr7(hw);
         uint32_t lane_win = w.wnb | (w.wtr7 << 7);        // the window in force at this lane's position
         uint64_t real = 0;
@@ -193,7 +197,7 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
                     // a new window from here on: positions that reuse the window change length
                     w.wnb = read_lane(sig, p);
                     w.wtr7 = read_lane(tr7, p);
-                    len = hw_fixed(hw) + t1 * w.wnb;
+                    len = hw_fixed(hw, lane) + t1 * w.wnb;
                     hop = zpc ? hop : len | flags;
                     if (lane > p) lane_win = w.wnb | (w.wtr7 << 7);
                 }
@@ -237,7 +241,7 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
                 if (pk & 0x200u) {
                     w.wnb = read_lane(sig, p);
                     w.wtr7 = read_lane(tr7, p);
-                    len = hw_fixed(hw) + t1 * w.wnb;
+                    len = hw_fixed(hw, lane) + t1 * w.wnb;
                     packed = len | (hw & (HW_T1 | HW_T2 | HW_EOS)) >> 2;
                     if (lane > p) lane_win = w.wnb | (w.wtr7 << 7);
                 }
@@ -259,43 +263,33 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
     return qn;
 }
 
-// The same for a region that lies well inside the image (no field of a point that starts in it can run off the
-// image), once a value window exists: nothing to check but the end marker and the capacity.  The walker visits
-// the region's rows of 64 positions in turn.  Lane l of the row's hop words is read with a scalar index, the
-// row's starts collect in a scalar mask, and lane r of two registers keeps the mask of row r; the chain of hops
-// itself is eight scalar instructions per hop (hop_chain()).  The queue is written once per region, lane r handing
-// over the starts of row r in order with the window in force at each (a '11' point changes it for the points
-// after it).
-// Returns the number of points queued; `handover`: the walk stopped before the region's end (w.cur says where)
-// and walk_region_careful() has the rest.
-
-// The chain of hops through the rows of a region, as one piece of assembly: the compiler's own code for such a
-// loop costs ten taken branches a row, and a lone wave pays a refill of its instruction buffer for each.  This
-// form has one taken branch per row and one per hop after a row's first.
+// The chain of hops through the rows of a region that lies well inside the image (no field of a point that starts
+// in it can run off the image) and well before the caller's capacity, as one piece of assembly: the compiler's own
+// code for such a loop costs ten taken branches a row, and a lone wave pays a refill of its instruction buffer for
+// each.  Here a plain hop is a lane read, a bit set and a compare, and every second hop a taken branch.
 //
-// State: row r (< 64) and position q in it; `real`: the starts found in the row so far; lane l of `hop` holds the
-// hop from position l of the row in its low byte and flags above (a run of '00' points, a '11' code, an end
-// marker); lane r of blo/bhi receives the finished mask of row r and lane r of rowwin the window in force where
-// the row begins; `found` counts the starts.  base: LDS byte address of this lane's hop word in row 0.
-// mode 0 starts at (r, q) with a fresh row; mode 1 resumes inside the row (hw/hop/real as left, hop recomputed by
-// the caller after a window change).
-// Returns 0 with r >= stoprow (the region's end, or where the caller wants a word) or found >= budget (the capacity
-// may fill up inside the next row), the row's mask stored; 2 before a hop that is a '11' code or an end marker
-// (kk holds its hop word, r/q/real say where): the caller's business.
-__device__ __forceinline__ uint32_t walk_rows(uint32_t mode, uint32_t& r, uint32_t& q, uint64_t& real, uint32_t& kk,
-                                              uint32_t& found, uint32_t budget, uint32_t stoprow, uint32_t win,
-                                              uint32_t& hw, uint32_t& hwn, uint32_t& hop, uint32_t& va, uint32_t& blo,
-                                              uint32_t& bhi, uint32_t& rowwin, uint32_t base)
+// State: row r (< 64) and position q in it; `real`: the starts found in the row so far; lane l of `nxt` holds the
+// place in the row (64 and more: in the rows after it) where the chain lands from position l, or something above
+// 511 where position l is not a plain hop: a run of '00' points, a '11' code, an end marker -- or a '10' code while
+// there is no window for it to reuse.  Lane r of blo/bhi receives the finished mask of row r and lane r of rowwin
+// the window in force where the row begins.  base: LDS byte address of this lane's hop word in row 0.
+// win: the value window in force (significant bits | trailing zeros << 7; 0: none yet); a '11' code replaces it and
+// with it the length of the positions that reuse the window.
+// Starts at (r, q) with a fresh row.  Returns 0 with r >= stoprow (the region's end, or where the caller wants a
+// word), the rows' masks stored and kk = the last hop (its length | HW_T1 or HW_RUN); 2 at an end marker or a '10'
+// code without a window (r/q/real say where and what the row had before it): the careful walk's.
+__device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t& real, uint32_t& kk, uint32_t stoprow,
+                                              uint32_t& win, uint32_t& blo, uint32_t& bhi, uint32_t& rowwin, uint32_t base)
 {
-    uint32_t code, t, vt;
+    uint32_t code, t, q2, len, lastpos, wnbx, vt, hw, hwn, nxt, va;
     uint32_t rlo = (uint32_t)real, rhi = (uint32_t)(real >> 32);
-    const uint32_t wnb = win & 127u;
     const uint64_t c5 = 0x5555555555555555ull;
     asm volatile(
         "s_mov_b32 s96, %[rlo]\n\t"
         "s_mov_b32 s97, %[rhi]\n\t"
-        "s_cmp_eq_u32 %[mode], 0\n\t"
-        "s_cbranch_scc0 4f\n\t"
+        "s_and_b32 %[wnbx], %[win], 127\n\t"
+        "s_cmp_eq_u32 %[wnbx], 0\n\t"
+        "s_cselect_b32 %[wnbx], 0x800000, %[wnbx]\n\t"   // no window yet: a '10' code lands nowhere
         // ---- a fresh row: its hop words and those of the row after it
         "v_lshl_add_u32 %[va], %[r], 8, %[base]\n\t"
         "ds_read_b32 %[hw], %[va]\n\t"
@@ -305,34 +299,75 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t mode, uint32_t& r, uint32
         "1:\n\t"
         "s_mov_b32 m0, %[r]\n\t"
         "v_bfe_u32 %[vt], %[hw], 10, 1\n\t"
-        "v_and_b32 %[hop], 0x1eff, %[hw]\n\t"
+        "v_and_b32 %[nxt], 0x800001ff, %[hw]\n\t"
         "v_writelane_b32 %[rowwin], %[win], m0\n\t"
-        "v_mad_u32_u24 %[hop], %[vt], %[wnb], %[hop]\n\t"
+        "v_mad_u32_u24 %[nxt], %[vt], %[wnbx], %[nxt]\n\t"
         "s_nop 1\n"
+        // ---- plain hops, two to a round (a lane read with a lane number that a lane read produced needs four
+        // instructions in between)
         "2:\n\t"
-        "v_readlane_b32 %[kk], %[hop], %[q]\n\t"
-        "s_and_b32 %[t], %[kk], 0x1a00\n\t"
-        "s_cbranch_scc1 6f\n\t"
-        "s_bitset1_b64 s[96:97], %[q]\n"
-        "3:\n\t"
-        "s_and_b32 %[t], %[kk], 0xff\n\t"
-        "s_add_u32 %[q], %[q], %[t]\n"
-        "4:\n\t"
+        "v_readlane_b32 %[q2], %[nxt], %[q]\n\t"
+        "s_bitset1_b64 s[96:97], %[q]\n\t"
+        "s_cmp_lt_u32 %[q2], 64\n\t"
+        "s_cbranch_scc0 20f\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[q], %[nxt], %[q2]\n\t"
+        "s_bitset1_b64 s[96:97], %[q2]\n\t"
         "s_cmp_lt_u32 %[q], 64\n\t"
+        "s_nop 0\n\t"
         "s_cbranch_scc1 2b\n\t"
-        // ---- the row is done
-        "s_mov_b32 m0, %[r]\n\t"
-        "s_bcnt1_i32_b64 %[t], s[96:97]\n\t"
-        "s_add_u32 %[found], %[found], %[t]\n\t"
+        "s_mov_b32 %[t], %[q]\n\t"      // the same way out as the first half: from q to q2
+        "s_mov_b32 %[q], %[q2]\n\t"
+        "s_mov_b32 %[q2], %[t]\n"
+        "20:\n\t"
+        "s_cmp_lt_u32 %[q2], 512\n\t"
+        "s_cbranch_scc1 30f\n\t"
+        // ---- position q is not a plain hop
+        "v_readlane_b32 %[kk], %[hw], %[q]\n\t"
+        "s_bitcmp1_b32 %[kk], 9\n\t"
+        "s_cbranch_scc0 22f\n\t"
+        "s_and_b32 %[q2], %[kk], 0x1ff\n\t"      // a run of '00' points: bits q, q + 2, ... up to where it lands
+        "s_sub_u32 %[t], %[q2], %[q]\n\t"
+        "s_sub_u32 %[t], 64, %[t]\n\t"
+        "s_lshr_b64 s[98:99], %[c5], %[t]\n\t"
+        "s_lshl_b64 s[98:99], s[98:99], %[q]\n\t"
+        "s_or_b64 s[96:97], s[96:97], s[98:99]\n\t"
+        "s_sub_u32 %[q], %[q2], 2\n\t"           // (the run's last point)
+        "s_cmp_lt_u32 %[q2], 64\n\t"
+        "s_cbranch_scc0 30f\n\t"
+        "s_mov_b32 %[q], %[q2]\n\t"
+        "s_branch 2b\n"
+        "22:\n\t"
+        "s_and_b32 %[t], %[kk], 0x1400\n\t"      // an end marker, or a '10' code with no window to reuse: not this loop's
+        "s_cbranch_scc1 29f\n\t"
+        // a '11' code: the window it declares is in force from the next point on, and the positions of the row that
+        // reuse the window change length
+        "s_lshr_b32 %[t], %[kk], 13\n\t"
+        "s_and_b32 %[win], %[t], 0x3fff\n\t"
+        "s_and_b32 %[wnbx], %[win], 127\n\t"
+        "v_and_b32 %[nxt], 0x800001ff, %[hw]\n\t"
+        "s_and_b32 %[q2], %[kk], 0x1ff\n\t"
+        "v_mad_u32_u24 %[nxt], %[vt], %[wnbx], %[nxt]\n\t"
+        "s_cmp_lt_u32 %[q2], 64\n\t"
+        "s_cbranch_scc0 30f\n\t"
+        "s_mov_b32 %[q], %[q2]\n\t"
+        "s_branch 2b\n"
+        "29:\n\t"
+        "s_bitset0_b64 s[96:97], %[q]\n\t"
+        "s_mov_b32 %[kk], 2\n\t"
+        "s_mov_b32 %[code], 2\n\t"
+        "s_branch 10f\n"
+        // ---- the row is done: the chain went from q to q2 >= 64
+        "30:\n\t"
+        "s_sub_u32 %[len], %[q2], %[q]\n\t"
+        "s_mov_b32 %[lastpos], %[q]\n\t"
         "v_writelane_b32 %[blo], s96, m0\n\t"
         "v_writelane_b32 %[bhi], s97, m0\n\t"
         "s_mov_b64 s[96:97], 0\n\t"
-        "s_lshr_b32 %[t], %[q], 6\n\t"
+        "s_lshr_b32 %[t], %[q2], 6\n\t"
         "s_add_u32 %[r], %[r], %[t]\n\t"
-        "s_and_b32 %[q], %[q], 63\n\t"
+        "s_and_b32 %[q], %[q2], 63\n\t"
         "s_cmp_ge_u32 %[r], %[stoprow]\n\t"
-        "s_cbranch_scc1 8f\n\t"
-        "s_cmp_ge_u32 %[found], %[budget]\n\t"
         "s_cbranch_scc1 8f\n\t"
         "s_cmp_eq_u32 %[t], 1\n\t"
         "s_cbranch_scc0 5f\n\t"
@@ -349,42 +384,34 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t mode, uint32_t& r, uint32
         "ds_read_b32 %[hwn], %[va]\n\t"
         "s_waitcnt lgkmcnt(1)\n\t"
         "s_branch 1b\n"
-        "6:\n\t"   // not a plain point
-        "s_bitcmp1_b32 %[kk], 9\n\t"
-        "s_cbranch_scc0 7f\n\t"
-        "s_and_b32 %[t], %[kk], 0xff\n\t"   // a run of '00' points: bits q, q + 2, ...
-        "s_sub_u32 %[t], 64, %[t]\n\t"
-        "s_lshr_b64 s[98:99], %[c5], %[t]\n\t"
-        "s_lshl_b64 s[98:99], s[98:99], %[q]\n\t"
-        "s_or_b64 s[96:97], s[96:97], s[98:99]\n\t"
-        "s_branch 3b\n"
-        "7:\n\t"
-        "s_mov_b32 %[code], 2\n\t"
-        "s_branch 9f\n"
-        "8:\n\t"
+        "8:\n\t"   // the last hop, for the caller: its length and whether it was a '10' code or part of a run
+        "v_readlane_b32 %[t], %[hw], %[lastpos]\n\t"
+        "s_and_b32 %[t], %[t], 0x600\n\t"
+        "s_or_b32 %[kk], %[len], %[t]\n\t"
         "s_mov_b32 %[code], 0\n"
-        "9:\n\t"
+        "10:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b32 %[rlo], s96\n\t"
         "s_mov_b32 %[rhi], s97\n"
-        : [code] "=&s"(code), [t] "=&s"(t), [vt] "=&v"(vt), [kk] "+s"(kk), [r] "+s"(r), [q] "+s"(q), [found] "+s"(found),
-          [rlo] "+s"(rlo), [rhi] "+s"(rhi), [hw] "+v"(hw), [hwn] "+v"(hwn), [hop] "+v"(hop), [va] "+v"(va), [blo] "+v"(blo),
-          [bhi] "+v"(bhi), [rowwin] "+v"(rowwin)
-        : [mode] "s"(mode), [budget] "s"(budget), [stoprow] "s"(stoprow), [win] "s"(win), [wnb] "s"(wnb), [c5] "s"(c5), [base] "v"(base)
+        : [code] "=&s"(code), [t] "=&s"(t), [q2] "=&s"(q2), [len] "=&s"(len), [lastpos] "=&s"(lastpos), [wnbx] "=&s"(wnbx),
+          [vt] "=&v"(vt), [hw] "=&v"(hw), [hwn] "=&v"(hwn), [nxt] "=&v"(nxt), [va] "=&v"(va),
+          [kk] "+s"(kk), [r] "+s"(r), [q] "+s"(q), [win] "+s"(win), [rlo] "+s"(rlo), [rhi] "+s"(rhi),
+          [blo] "+v"(blo), [bhi] "+v"(bhi), [rowwin] "+v"(rowwin)
+        : [stoprow] "s"(stoprow), [c5] "s"(c5), [base] "v"(base)
         : "scc", "m0", "s96", "s97", "s98", "s99", "memory");
     real = ((uint64_t)rhi << 32) | rlo;
     return code;
 }
 
-// The same for a region that lies well inside the image (no field of a point that starts in it can run off the
-// image), once a value window exists: nothing to check but the end marker and the capacity.  walk_rows() follows
-// the hops; what it leaves to this function are window changes, and strides: where the last point reused the
-// window, 64 candidate starts that point's length apart are tested with one gathered read -- a stream of
-// equal-sized points is taken 64 points at a time.  The queue is written once per region, lane r handing over
-// the starts of row r in order with the window in force at each (a '11' point changes it for the points after it).
+// A region that lies well inside the image and ends well before the capacity is full (a region holds RPOS / 2 points
+// at most): nothing to check but the end marker and '10' codes before the first window.  walk_rows() follows the hops; what it leaves to this function are strides: where the last
+// point reused the window, candidate starts that point's length apart are tested with gathered reads, up to 256 at
+// a time -- a stream of equal-sized points is taken a region at a time.  The queue is written once per region, lane
+// r handing over the starts of row r in order with the window in force at each (a '11' point changes it for the
+// points after it).
 // Returns the number of points queued; `handover`: the walk stopped before the region's end (w.cur says where)
 // and walk_region_careful() has the rest.
-__device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t k, uint32_t cap, uint32_t lane, bool& handover)
+__device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t k, uint32_t lane, bool& handover)
 {
     uint32_t* const qd = L.queue[k & 1u];
     const uint32_t* const hrow = L.hopw + (k & 1u) * RPOS + lane;
@@ -392,10 +419,6 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     uint32_t p = (uint32_t)w.cur & (RPOS - 1);     // position inside the region
     uint32_t win = w.wnb | (w.wtr7 << 7);          // the value window in force: significant bits | trailing zeros << 7
     uint32_t kk = w.last_t1 ? (w.last_len | HW_T1) : w.last_len;   // the last hop
-    uint32_t found = 0;
-    // points the region may still take before the capacity could fill up inside a row (a row holds 32 at most)
-    const uint32_t left = cap - w.found_total;     // (> 0: the careful walk stops at the capacity)
-    const uint32_t budget = left > 32 ? left - 32 : 0u;
     uint32_t blo = 0, bhi = 0, rowwin = 0;         // lane r: the starts of row r, the window in force where the row begins
     uint32_t next_try = (p >> 6) + w.cool;         // the row from which strides are tried again
     uint32_t backoff = 8;
@@ -403,67 +426,71 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     uint32_t lastgen = ~0u;                        // the last row the chain went through hop by hop
     handover = false;
     uint32_t r = p >> 6, q = p & 63u;
-    uint32_t hw = 0, hwn = 0, hop = 0, va = 0;
     uint64_t real = 0;
-    uint32_t mode = 0;
+    GTSC_WG_WALK_BEGIN(w)
     while (r < RW) {
-        if (mode == 0) {
-            if (found >= budget) { handover = true; break; }
-            // ---- points of equal length: 64 candidate starts a stride apart
-            if ((kk & HW_T1) && !(kk & HW_RUN) && r >= next_try) {
-                const uint32_t s = kk & 255u;
-                const uint32_t cand = r * 64 + q + lane * s;
-                const bool inreg = cand < RPOS;
-                const uint32_t hc = inreg ? hrow[(int32_t)cand - (int32_t)lane] : HW_EOS;
-                const uint32_t lc = hw_fixed(hc) + ((hc >> 10) & 1u) * (win & 127u);
-                const bool ok = (hc & (HW_T2 | HW_EOS)) == 0 && lc == s && found + lane < left;
-                const uint64_t bad = lanes(!ok);
-                const uint32_t js = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
-                if (js >= 4) {
-                    if (lane < js) atomicOr(reinterpret_cast<unsigned long long*>(&L.sbits[cand >> 6]), 1ull << (cand & 63u));
-                    // (rows the stride passes through get the window in force: it does not change on the way; row r
-                    // has its own from the hops that came through it, if any did)
-                    if (lane > r || (lane == r && lastgen != r)) rowwin = win;
-                    strided = true;
-                    found += js;
-                    const uint32_t pn = r * 64 + q + js * s;
-                    r = pn >> 6; q = pn & 63u;
-                    kk = (read_lane(hc, js - 1) & HW_T1) ? (s | HW_T1) : s;
-                    backoff = 8;
-                    continue;
-                }
-                // the chain broke right away (not merely at the region's end): hops for a while
-                if (read_lane((uint32_t)inreg, js)) { next_try = r + backoff; backoff = backoff < 64 ? backoff * 2 : 64u; }
+        // ---- points of equal length: candidate starts a stride apart, 64 per gathered read and as many reads as
+        // the rest of the region has room for (all in flight together)
+        if ((kk & HW_T1) && !(kk & HW_RUN) && r >= next_try) {
+            const uint32_t s = kk & 255u, start = r * 64 + q;
+            const uint32_t groups = (RPOS - start + 64 * s - 1) / (64 * s);   // >= 1
+            const uint32_t G = groups < 4 ? groups : 4u;
+            uint32_t hc[4];
+#pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                const uint32_t cand = start + (lane + 64 * g) * s;
+                hc[g] = (g < G && cand < RPOS) ? hrow[(int32_t)cand - (int32_t)lane] : HW_EOS;
             }
+            uint32_t js = 0, last_hc = 0;
+            bool in_at_break = false;
+#pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                if (g < G && js == 64 * g) {
+                    const uint32_t cand = start + (lane + 64 * g) * s;
+                    const uint32_t lc = hw_fixed(hc[g], cand & 63u) + ((hc[g] >> 10) & 1u) * (win & 127u);
+                    const bool ok = (hc[g] & (HW_T2 | HW_EOS)) == 0 && lc == s;
+                    const uint64_t bad = lanes(!ok);
+                    const uint32_t jg = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                    if (lane < jg && (g > 0 || jg >= 4)) atomicOr(reinterpret_cast<unsigned long long*>(&L.sbits[cand >> 6]), 1ull << (cand & 63u));
+                    if (jg) last_hc = read_lane(hc[g], jg - 1);
+                    if (jg < 64) in_at_break = read_lane((uint32_t)(cand < RPOS), jg) != 0;
+                    js += jg;
+                }
+            }
+            if (js >= 4) {
+                // (rows the stride passes through get the window in force: it does not change on the way; row r
+                // has its own from the hops that came through it, if any did)
+                if (lane > r || (lane == r && lastgen != r)) rowwin = win;
+                strided = true;
+                const uint32_t pn = start + js * s;
+                r = pn >> 6; q = pn & 63u;
+                kk = (last_hc & HW_T1) ? (s | HW_T1) : s;
+                backoff = 8;
+                GTSC_WG_WALK_COUNT(w, tw_strides)
+                GTSC_WG_WALK_TICK(w, tw_stride)
+                continue;
+            }
+            // the chain broke right away (not merely at the region's end): hops for a while
+            if (in_at_break) { next_try = r + backoff; backoff = backoff < 64 ? backoff * 2 : 64u; }
         }
         // ---- hops: to the region's end, or to the row where a stride may be tried again
         const uint32_t stoprow = next_try > r && next_try < RW ? next_try : RW;
-        lastgen = r;   // (and the rows after it: a stride only ever starts where the hops stopped)
-        const uint32_t code = walk_rows(mode, r, q, real, kk, found, budget, stoprow, win, hw, hwn, hop, va, blo, bhi, rowwin, base);
-        mode = 0;
+        GTSC_WG_WALK_TICK(w, tw_stride)
+        const uint32_t code = walk_rows(r, q, real, kk, stoprow, win, blo, bhi, rowwin, base);
+        GTSC_WG_WALK_COUNT(w, tw_calls)
+        GTSC_WG_WALK_TICK(w, tw_rows)
         if (code == 2) {
-            if (kk & HW_T2) {
-                // a new window from here on: positions that reuse the window change length
-                win = (read_lane(hw, q) >> 13) & 0x3FFFu;
-                hop = (hw & HW_HOP) + ((hw >> 10) & 1u) * (win & 127u);
-                real |= 1ull << q;
-                q += kk & 255u;
-                mode = 1;
-                lastgen = r;
-            } else {
-                // what looks like the end marker: the careful walk has it (the starts of the row so far go along)
-                blo = write_lane(blo, (uint32_t)real, r);
-                bhi = write_lane(bhi, (uint32_t)(real >> 32), r);
-                found += (uint32_t)__builtin_popcountll(real);
-                handover = true;
-                break;
-            }
-        } else {
-            lastgen = r - 1;
-            if (found >= budget && r < RW) { handover = true; break; }
+            // what looks like the end marker, or a '10' code before any window: the careful walk has it (the starts
+            // of the row so far go along)
+            blo = write_lane(blo, (uint32_t)real, r);
+            bhi = write_lane(bhi, (uint32_t)(real >> 32), r);
+            handover = true;
+            break;
         }
+        lastgen = r - 1;
     }
     p = r * 64 + q;
+    GTSC_WG_WALK_TICK(w, tw_stride)
     // ---- the queue: lane r hands over the starts of row r
     uint64_t wb = ((uint64_t)bhi << 32) | blo;
     if (strided) { wave_sync(); wb |= L.sbits[lane]; L.sbits[lane] = 0; }
@@ -485,8 +512,10 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     w.last_len = (kk & HW_RUN) ? 2u : (kk & 255u);
     w.last_t1 = (kk & HW_T1) != 0 && !(kk & HW_RUN);
     w.cool = next_try > r && r < RW ? next_try - r : 0u;
+    const uint32_t found = read_lane(incl, 63);
     w.found_total += found;
-    return read_lane(incl, 63);
+    GTSC_WG_WALK_TICK(w, tw_queue)
+    return found;
 }
 
 // Decompresses block `s` with the whole workgroup of NW waves.
@@ -572,8 +601,13 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                 uint32_t qn = 0;
                 if (!stop_prev) {
                     bool rest = true;
-                    if (wk.wnb != 0 && (uint64_t)(k + 1) * RPOS + 256 < limit) qn = walk_region_fast(wk, L, k, cap, lane, rest);
-                    if (rest) qn = walk_region_careful(wk, L, k, limit, cap, lane, qn);
+                    if ((uint64_t)(k + 1) * RPOS + 256 < limit && cap - wk.found_total > QCAP + 64) qn = walk_region_fast(wk, L, k, lane, rest);
+                    if (rest) {
+                        GTSC_WG_WALK_COUNT(wk, tw_handover)
+                        GTSC_WG_WALK_BEGIN(wk)
+                        qn = walk_region_careful(wk, L, k, limit, cap, lane, qn);
+                        GTSC_WG_WALK_TICK(wk, tw_careful)
+                    }
                 }
                 if (lane == 0) {
                     L.qcount[slot] = qn;
@@ -720,6 +754,7 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
             qprev = qnow;
         }
         GTSC_WG_STAMP_PRINT
+        GTSC_WG_WALK_PRINT(wk)
     }
     uint32_t st = 0;
     if (!clean_end || serial) {
