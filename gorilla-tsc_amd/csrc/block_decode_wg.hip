@@ -105,7 +105,95 @@ struct WgLds {
     uint32_t stop, clean;          // the walker met the end of the stream or something for the serial decoder
     uint32_t endrel, endwin;       // where the last queued point of the region ends, and the window after it
     uint64_t sbits[RW];            // the walker's own: starts found by strides in the region under way (bit l of word r: position 64 r + l)
+    uint8_t land[2 * RPOS];        // landing tables: land[p % (2 RPOS)] = where the chain that enters p's row at p leaves the row
+    uint32_t landwnb[2];           // the window size (significant bits) the tables of a region were made for
+    uint32_t curwnb;               // the walker's window size when it last reported
+    uint32_t want_tables;          // ... and whether it has use for tables (not while strides carry it)
+    uint32_t pad_[14];             // (a row's table is read one row ahead, past the last row too)
 };
+
+// Where the chain leaves a row, for each of the 64 places it may enter it -- worked out by the classifier waves for
+// the rows they classified, with one pointer-doubling pass per row: lane l starts with where position l lands and
+// replaces it six times by where that place lands, until it is outside the row (a hop is two bits at least, a run
+// of '00' points is one hop: 32 hops at most).  A '10' code's length needs the window size, which the walker only
+// knows for certain when it gets there: the tables are made for the size it last reported (`wnb`; 0: no window yet)
+// and the walker uses them while that is the size in force.  LAND_STOP: the path from that place meets a '11' code,
+// an end marker or a '10' code without a window -- the walker goes through such a row hop by hop.
+constexpr uint32_t LAND_STOP = 255;
+// the tables of rows [row0, row0 + 4) of a region (four chains of dependent lane reads in flight together)
+__device__ __forceinline__ void make_landing_tables(WgLds& L, uint32_t region, uint32_t row0, uint32_t wnb, uint32_t lane)
+{
+    const uint32_t at = (region & 1u) * RPOS + row0 * 64 + lane;
+    uint32_t n[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t hw = L.hopw[at + 64 * i];
+        n[i] = (hw & HW_NEXT) + ((hw >> 10) & 1u) * wnb;   // < 255
+        if ((hw & (HW_T2 | HW_EOS)) || ((hw & HW_T1) && wnb == 0)) n[i] = LAND_STOP;
+    }
+    // (six doublings at most: 64 hops; rows of few points are through after two or three)
+    for (int step = 0; step < 6 && any_lane((n[0] & n[1] & n[2] & n[3]) < 64 || n[0] < 64 || n[1] < 64 || n[2] < 64 || n[3] < 64); step++) {
+        uint32_t m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) m[i] = (uint32_t)__shfl((int)n[i], (int)(n[i] & 63u), 64);
+#pragma unroll
+        for (int i = 0; i < 4; i++) n[i] = n[i] < 64 ? m[i] : n[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) L.land[at + 64 * i] = (uint8_t)n[i];
+}
+
+// Follows the chain through rows by their landing tables: one lane read per row.  Lane r of `entry` receives the
+// place where the chain entered row r.  lbase: LDS byte address of this lane's entry in the table of row 0.
+// Returns 0 with r >= stoprow (q: the place in that row), 1 at a row whose table says LAND_STOP for the place the
+// chain enters it (r, q: that row and place; nothing recorded for it).
+__device__ __forceinline__ uint32_t chase_rows(uint32_t& r, uint32_t& q, uint32_t& entry, uint32_t lbase, uint32_t stoprow)
+{
+    uint32_t code, t, adv, ja, jb, va;
+    asm volatile(
+        "v_lshl_add_u32 %[va], %[r], 6, %[lbase]\n\t"
+        "ds_read_u8 %[ja], %[va]\n\t"
+        "ds_read_u8 %[jb], %[va] offset:64\n\t"
+        "s_waitcnt lgkmcnt(1)\n"
+        "1:\n\t"
+        "v_readlane_b32 %[t], %[ja], %[q]\n\t"
+        "s_cmp_eq_u32 %[t], 255\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "s_mov_b32 m0, %[r]\n\t"
+        "s_lshr_b32 %[adv], %[t], 6\n\t"
+        "v_writelane_b32 %[entry], %[q], m0\n\t"
+        "s_add_u32 %[r], %[r], %[adv]\n\t"
+        "s_and_b32 %[q], %[t], 63\n\t"
+        "s_cmp_ge_u32 %[r], %[stoprow]\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "s_cmp_eq_u32 %[adv], 1\n\t"
+        "s_cbranch_scc0 5f\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mov_b32 %[ja], %[jb]\n\t"
+        "v_add_u32 %[va], 64, %[va]\n\t"
+        "ds_read_u8 %[jb], %[va] offset:64\n\t"
+        "s_branch 1b\n"
+        "5:\n\t"   // the chain hopped over a whole row
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshl_add_u32 %[va], %[r], 6, %[lbase]\n\t"
+        "ds_read_u8 %[ja], %[va]\n\t"
+        "ds_read_u8 %[jb], %[va] offset:64\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "s_branch 1b\n"
+        "8:\n\t"
+        "s_mov_b32 %[code], 0\n\t"
+        "s_branch 10f\n"
+        "9:\n\t"
+        "s_mov_b32 %[code], 1\n"
+        "10:\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [code] "=&s"(code), [t] "=&s"(t), [adv] "=&s"(adv), [ja] "=&v"(ja), [jb] "=&v"(jb), [va] "=&v"(va),
+          [r] "+s"(r), [q] "+s"(q), [entry] "+v"(entry)
+        : [lbase] "v"(lbase), [stoprow] "s"(stoprow)
+        : "scc", "m0", "memory");
+    return code;
+}
+
 
 // A word of LDS that another wave wrote before the last barrier, as a scalar.
 __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p)
@@ -134,6 +222,9 @@ struct Walk {
     uint32_t cool;           // rows to pass before strides are tried again
     uint32_t found_total;    // points found so far, the block's first one included
     bool stop, clean_end;
+    uint32_t backoff;        // rows to the stride attempt after the next one that fails
+    bool last_known;         // last_len / last_t1 say what the last point was
+    bool want_tables;        // the last region was not one that strides carried
     GTSC_WG_WALK_DECL
 };
 
@@ -404,11 +495,14 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t
 }
 
 // A region that lies well inside the image and ends well before the capacity is full (a region holds RPOS / 2 points
-// at most): nothing to check but the end marker and '10' codes before the first window.  walk_rows() follows the hops; what it leaves to this function are strides: where the last
-// point reused the window, candidate starts that point's length apart are tested with gathered reads, up to 256 at
-// a time -- a stream of equal-sized points is taken a region at a time.  The queue is written once per region, lane
-// r handing over the starts of row r in order with the window in force at each (a '11' point changes it for the
-// points after it).
+// at most): nothing to check but the end marker and '10' codes before the first window.  Three ways through it:
+// chase_rows() while the landing tables fit the window in force, a lane read per row -- the starts inside those rows
+// are found afterwards, lane r walking row r from where the chain entered it, all rows at once; walk_rows(), hop by
+// hop, through rows whose table says stop and wherever the tables were made for another window size; and strides:
+// where the last point reused the window, candidate starts that point's length apart are tested with gathered
+// reads, up to 256 at a time -- a stream of long equal-sized points is taken a region at a time.  The queue is
+// written once per region, lane r handing over the starts of row r in order with the window in force at each (a
+// '11' point changes it for the points after it).
 // Returns the number of points queued; `handover`: the walk stopped before the region's end (w.cur says where)
 // and walk_region_careful() has the rest.
 __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t k, uint32_t lane, bool& handover)
@@ -421,78 +515,122 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     uint32_t kk = w.last_t1 ? (w.last_len | HW_T1) : w.last_len;   // the last hop
     uint32_t blo = 0, bhi = 0, rowwin = 0;         // lane r: the starts of row r, the window in force where the row begins
     uint32_t next_try = (p >> 6) + w.cool;         // the row from which strides are tried again
-    uint32_t backoff = 8;
+    uint32_t backoff = w.backoff;                  // rows to the next attempt after one that failed (8 ... 1024)
+    bool kk_known = w.last_known;                  // kk says what the last hop was (chase_rows() does not look)
     bool strided = false;
+    uint32_t stride_points = 0;
     uint32_t lastgen = ~0u;                        // the last row the chain went through hop by hop
     handover = false;
     uint32_t r = p >> 6, q = p & 63u;
     uint64_t real = 0;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)(L.land + (k & 1u) * RPOS + lane);
+    const uint32_t table_wnb = lds_peek(&L.landwnb[k & 1u]);
+    uint32_t entry = ~0u;                          // lane r: where the chain entered row r by its landing table (none: ~0)
     GTSC_WG_WALK_BEGIN(w)
-    while (r < RW) {
-        // ---- points of equal length: candidate starts a stride apart, 64 per gathered read and as many reads as
-        // the rest of the region has room for (all in flight together)
-        if ((kk & HW_T1) && !(kk & HW_RUN) && r >= next_try) {
-            const uint32_t s = kk & 255u, start = r * 64 + q;
-            const uint32_t groups = (RPOS - start + 64 * s - 1) / (64 * s);   // >= 1
-            const uint32_t G = groups < 4 ? groups : 4u;
-            uint32_t hc[4];
-#pragma unroll
-            for (uint32_t g = 0; g < 4; g++) {
-                const uint32_t cand = start + (lane + 64 * g) * s;
-                hc[g] = (g < G && cand < RPOS) ? hrow[(int32_t)cand - (int32_t)lane] : HW_EOS;
-            }
-            uint32_t js = 0, last_hc = 0;
-            bool in_at_break = false;
-#pragma unroll
-            for (uint32_t g = 0; g < 4; g++) {
-                if (g < G && js == 64 * g) {
-                    const uint32_t cand = start + (lane + 64 * g) * s;
-                    const uint32_t lc = hw_fixed(hc[g], cand & 63u) + ((hc[g] >> 10) & 1u) * (win & 127u);
-                    const bool ok = (hc[g] & (HW_T2 | HW_EOS)) == 0 && lc == s;
-                    const uint64_t bad = lanes(!ok);
-                    const uint32_t jg = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
-                    if (lane < jg && (g > 0 || jg >= 4)) atomicOr(reinterpret_cast<unsigned long long*>(&L.sbits[cand >> 6]), 1ull << (cand & 63u));
-                    if (jg) last_hc = read_lane(hc[g], jg - 1);
-                    if (jg < 64) in_at_break = read_lane((uint32_t)(cand < RPOS), jg) != 0;
-                    js += jg;
-                }
-            }
-            if (js >= 4) {
-                // (rows the stride passes through get the window in force: it does not change on the way; row r
-                // has its own from the hops that came through it, if any did)
-                if (lane > r || (lane == r && lastgen != r)) rowwin = win;
-                strided = true;
-                const uint32_t pn = start + js * s;
-                r = pn >> 6; q = pn & 63u;
-                kk = (last_hc & HW_T1) ? (s | HW_T1) : s;
-                backoff = 8;
-                GTSC_WG_WALK_COUNT(w, tw_strides)
-                GTSC_WG_WALK_TICK(w, tw_stride)
-                continue;
-            }
-            // the chain broke right away (not merely at the region's end): hops for a while
-            if (in_at_break) { next_try = r + backoff; backoff = backoff < 64 ? backoff * 2 : 64u; }
-        }
-        // ---- hops: to the region's end, or to the row where a stride may be tried again
-        const uint32_t stoprow = next_try > r && next_try < RW ? next_try : RW;
-        GTSC_WG_WALK_TICK(w, tw_stride)
-        const uint32_t code = walk_rows(r, q, real, kk, stoprow, win, blo, bhi, rowwin, base);
+    // hops through rows [r, stop): false when the careful walk has to take over
+    auto hop_rows = [&](uint32_t stop) -> bool {
+        const uint32_t code = walk_rows(r, q, real, kk, stop, win, blo, bhi, rowwin, base);
         GTSC_WG_WALK_COUNT(w, tw_calls)
         GTSC_WG_WALK_TICK(w, tw_rows)
+        kk_known = true;
         if (code == 2) {
-            // what looks like the end marker, or a '10' code before any window: the careful walk has it (the starts
-            // of the row so far go along)
+            // what looks like the end marker, or a '10' code before any window (the starts of the row so far go along)
             blo = write_lane(blo, (uint32_t)real, r);
             bhi = write_lane(bhi, (uint32_t)(real >> 32), r);
             handover = true;
-            break;
+            return false;
         }
         lastgen = r - 1;
+        return true;
+    };
+    while (r < RW) {
+        if (r >= next_try) {
+            // ---- time to see whether the points have become equal in length (once in a while: an attempt costs as
+            // much as twenty rows by table)
+            if (!kk_known) {
+                if (!hop_rows(r + 1)) break;
+                continue;
+            }
+            bool moved = false, broke_inside = true;
+            if ((kk & HW_T1) && !(kk & HW_RUN)) {
+                // candidate starts a stride apart, 64 per gathered read and as many reads as the rest of the region
+                // has room for (all in flight together)
+                const uint32_t s = kk & 255u, start = r * 64 + q;
+                const uint32_t groups = (RPOS - start + 64 * s - 1) / (64 * s);   // >= 1
+                const uint32_t G = groups < 4 ? groups : 4u;
+                uint32_t hc[4];
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    const uint32_t cand = start + (lane + 64 * g) * s;
+                    hc[g] = (g < G && cand < RPOS) ? hrow[(int32_t)cand - (int32_t)lane] : HW_EOS;
+                }
+                uint32_t js = 0, last_hc = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    if (g < G && js == 64 * g) {
+                        const uint32_t cand = start + (lane + 64 * g) * s;
+                        const uint32_t lc = hw_fixed(hc[g], cand & 63u) + ((hc[g] >> 10) & 1u) * (win & 127u);
+                        const bool ok = (hc[g] & (HW_T2 | HW_EOS)) == 0 && lc == s;
+                        const uint64_t bad = lanes(!ok);
+                        const uint32_t jg = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                        if (lane < jg && (g > 0 || jg >= 4)) atomicOr(reinterpret_cast<unsigned long long*>(&L.sbits[cand >> 6]), 1ull << (cand & 63u));
+                        if (jg) last_hc = read_lane(hc[g], jg - 1);
+                        if (jg < 64) broke_inside = read_lane((uint32_t)(cand < RPOS), jg) != 0;
+                        js += jg;
+                    }
+                }
+                GTSC_WG_WALK_TICK(w, tw_stride)
+                if (js >= 4) {
+                    // (rows the stride passes through get the window in force: it does not change on the way; row r
+                    // has its own from the hops that came through it, if any did)
+                    if (lane > r || (lane == r && lastgen != r)) rowwin = win;
+                    strided = true;
+                    stride_points += js;
+                    const uint32_t pn = start + js * s;
+                    r = pn >> 6; q = pn & 63u;
+                    kk = (last_hc & HW_T1) ? (s | HW_T1) : s;
+                    moved = true;
+                    GTSC_WG_WALK_COUNT(w, tw_strides)
+                    if (js >= 32 || !broke_inside) { backoff = 8; continue; }   // worth it (or cut short by the region's end): again right away
+                }
+            }
+            // not worth it: rows by table or by hops for a while (longer every time)
+            if (broke_inside) { next_try = r + backoff; backoff = backoff < 1024 ? backoff * 2 : 1024u; }
+            if (moved) continue;
+        }
+        const uint32_t stop = next_try > r && next_try < RW ? next_try : RW;
+        if ((win & 127u) == table_wnb) {
+            // ---- by the landing tables, while they fit the window
+            const uint32_t before = entry;
+            const uint32_t code = chase_rows(r, q, entry, lbase, stop);
+            if (entry != before) rowwin = win;     // (the rows just entered: the window does not change on the way)
+            kk = 0; kk_known = false;
+            GTSC_WG_WALK_TICK(w, tw_chase)
+            // a row the table leaves to the hops: this one row
+            if (code == 1 && !hop_rows(r + 1)) break;
+            continue;
+        }
+        // ---- hops: to the region's end, or to the row where a stride may be tried again
+        if (!hop_rows(stop)) break;
     }
     p = r * 64 + q;
     GTSC_WG_WALK_TICK(w, tw_stride)
-    // ---- the queue: lane r hands over the starts of row r
+    // ---- the starts inside the rows entered by table: lane r walks row r (no '11' code and no end marker on the way)
     uint64_t wb = ((uint64_t)bhi << 32) | blo;
+    {
+        uint32_t pos = entry < 64 ? entry : 64u;
+        const uint32_t wn = rowwin & 127u;
+        while (any_lane(pos < 64)) {
+            if (pos < 64) {
+                const uint32_t h = hrow[(int32_t)(lane * 64 + pos) - (int32_t)lane];
+                const uint32_t nx = (h & HW_NEXT) + ((h >> 10) & 1u) * wn;
+                wb |= (h & HW_RUN) ? (0x5555555555555555ull >> (64u - (nx - pos))) << pos : 1ull << pos;
+                pos = nx;
+            }
+        }
+    }
+    GTSC_WG_WALK_TICK(w, tw_enum)
+    // ---- the queue: lane r hands over the starts of row r
     if (strided) { wave_sync(); wb |= L.sbits[lane]; L.sbits[lane] = 0; }
     const uint32_t c = (uint32_t)__builtin_popcountll(wb);
     const uint32_t incl = wave_inclusive_sum(c);
@@ -511,9 +649,13 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     w.wnb = win & 127u; w.wtr7 = win >> 7;
     w.last_len = (kk & HW_RUN) ? 2u : (kk & 255u);
     w.last_t1 = (kk & HW_T1) != 0 && !(kk & HW_RUN);
-    w.cool = next_try > r && r < RW ? next_try - r : 0u;
+    w.cool = next_try > r ? next_try - r : 0u;
+    w.backoff = backoff;
+    w.last_known = kk_known;
     const uint32_t found = read_lane(incl, 63);
     w.found_total += found;
+    w.want_tables = 4 * stride_points < 3 * found || found == 0;
+
     GTSC_WG_WALK_TICK(w, tw_queue)
     return found;
 }
@@ -586,15 +728,22 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
             }
         };
         classify_region(0, tid, NT);
+        // (a wave classifies whole rows -- four positions per lane, 256 per pass: the tables of its rows are its own work)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        make_landing_tables(L, 0, 4 * wave, 0u, lane);
+        if (tid == 0) { L.landwnb[0] = 0; L.landwnb[1] = 0xFFFFFFFFu; L.curwnb = 0; L.want_tables = 1; }
         wg_barrier();
 
-        Walk wk{pos, 0u, 0u, 0u, false, 0u, 1u, false, false};
+        Walk wk{pos, 0u, 0u, 0u, false, 0u, 1u, false, false, 8u, true, true};
         GTSC_WG_STAMP_DECL
         bool stop_prev = false;       // the walker stopped in the tick before: this one only emits
         uint32_t qprev = 0;           // points the walker queued in the tick before
         for (uint32_t k = 0;; k++) {
             const uint32_t slot = k & 1u, pslot = slot ^ 1u;
             uint64_t s_loc[MB], x_loc[MB];
+            // (what the walker wrote before the barrier that ended the tick before)
+            const uint32_t wnb_seen = lds_peek(&L.curwnb);
+            const bool want_seen = lds_peek(&L.want_tables) != 0;
             // ---- the walker in region k; the others classify region k + 1 and parse what was queued in region k - 1
             GTSC_WG_TICK(tk_other)
             if (wave == 0) {
@@ -613,6 +762,8 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                     L.qcount[slot] = qn;
                     L.stop = wk.stop ? 1u : 0u;
                     L.clean = wk.clean_end ? 1u : 0u;
+                    L.curwnb = wk.wnb;
+                    L.want_tables = wk.want_tables ? 1u : 0u;
                     L.kb[slot] = 0xFFFFFFFFu;   // (for the tick after this one)
                     L.anydd[slot] = 0;
                 }
@@ -621,7 +772,17 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                 const uint32_t lw = (k + 2) * RW + 1 + lane;   // words [(k+2) RW + 1, (k+3) RW]: what region k + 2's positions look at
                 if (!stop_prev) {
                     if (wave == 1) landing = word(lw);
-                    classify_region(k + 1, (wave - 1) * 64 + lane, NH * 64);
+                    // four rows per helper wave -- and the four that leaves over to the last wave, which is the last to
+                    // get points to parse
+                    classify_region(k + 1, (wave - 1) * 64 + lane, RPOS);
+                    if (wave == NH) classify_region(k + 1, NH * 64 + lane, RPOS);
+                    // ... and the landing tables of the same rows, for the window size the walker had when the tick
+                    // began -- unless the stream is one the strides take, which do not use them
+                    if (want_seen) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        make_landing_tables(L, k + 1, 4 * (wave - 1), wnb_seen, lane);
+                        if (wave == NH) make_landing_tables(L, k + 1, 4 * NH, wnb_seen, lane);
+                    }
                 }
                 GTSC_WG_TICK(tk_x1)
 #pragma unroll
@@ -670,6 +831,15 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
             const uint32_t qnow = lds_peek(&L.qcount[slot]);
             const bool stop_now = lds_peek(&L.stop) != 0;
             if (stop_now) clean_end = lds_peek(&L.clean) != 0;
+            // ---- the walker has changed its window size under way: the landing tables of region k + 1 once more, four
+            // rows per wave
+            if (!stop_prev && !stop_now) {
+                const uint32_t wnb_now = lds_peek(&L.curwnb);
+                const bool again = want_seen && wnb_now != wnb_seen;
+                if (again) make_landing_tables(L, k + 1, 4 * wave, wnb_now, lane);
+                if (tid == 0) L.landwnb[pslot] = want_seen ? wnb_now : 0xFFFFFFFFu;
+                if (again && !qprev) wg_barrier();   // (with points to emit, the barrier below stands between the tables and their use)
+            }
             uint32_t kbv = 0xFFFFFFFFu;
             const uint32_t nb = (qprev + 63) / 64;
             if (qprev) {

@@ -119,11 +119,11 @@ constexpr bool DIAG_STAMPED = false;
 #ifdef GTSC_WG_STAMP
 #define GTSC_WG_STAMP_DECL uint64_t tk_other = 0, tk_x1 = 0, tk_x2 = 0, tk_b1 = 0, tk_y = 0, tk_b2 = 0, tk_z = 0, tk_prev = __builtin_amdgcn_s_memtime(); uint32_t tk_ticks = 0;
 #define GTSC_WG_TICK(acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tk_prev; tk_prev = now_; __builtin_amdgcn_sched_barrier(0); }
-#define GTSC_WG_WALK_DECL uint64_t tw_rows = 0, tw_stride = 0, tw_queue = 0, tw_careful = 0, tw_prev = 0; uint32_t tw_calls = 0, tw_strides = 0, tw_handover = 0;
+#define GTSC_WG_WALK_DECL uint64_t tw_rows = 0, tw_stride = 0, tw_queue = 0, tw_careful = 0, tw_chase = 0, tw_enum = 0, tw_prev = 0; uint32_t tw_calls = 0, tw_strides = 0, tw_handover = 0;
 #define GTSC_WG_WALK_BEGIN(W_) { __builtin_amdgcn_sched_barrier(0); (W_).tw_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define GTSC_WG_WALK_TICK(W_, acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); (W_).acc_ += now_ - (W_).tw_prev; (W_).tw_prev = now_; __builtin_amdgcn_sched_barrier(0); }
 #define GTSC_WG_WALK_COUNT(W_, cnt_) (W_).cnt_++;
-#define GTSC_WG_WALK_PRINT(W_) if (lane == 0 && wave == 0) printf("walker: rows %llu (%u calls) strides %llu (%u) queue %llu careful %llu (%u handovers)\n", (unsigned long long)(W_).tw_rows, (W_).tw_calls, (unsigned long long)(W_).tw_stride, (W_).tw_strides, (unsigned long long)(W_).tw_queue, (unsigned long long)(W_).tw_careful, (W_).tw_handover);
+#define GTSC_WG_WALK_PRINT(W_) if (lane == 0 && wave == 0) printf("walker: chase %llu enum %llu rows %llu (%u calls) strides %llu (%u) queue %llu careful %llu (%u handovers)\n", (unsigned long long)(W_).tw_chase, (unsigned long long)(W_).tw_enum, (unsigned long long)(W_).tw_rows, (W_).tw_calls, (unsigned long long)(W_).tw_stride, (W_).tw_strides, (unsigned long long)(W_).tw_queue, (unsigned long long)(W_).tw_careful, (W_).tw_handover);
 #define GTSC_WG_STAMP_PRINT if (lane == 0 && wave < 2) printf("wave %u: x1 %llu x2 %llu b1 %llu y %llu b2 %llu z %llu other %llu\n", wave, (unsigned long long)tk_x1, (unsigned long long)tk_x2, (unsigned long long)tk_b1, (unsigned long long)tk_y, (unsigned long long)tk_b2, (unsigned long long)tk_z, (unsigned long long)tk_other);
 #else
 #define GTSC_WG_STAMP_DECL
