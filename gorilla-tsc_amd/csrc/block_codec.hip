@@ -913,31 +913,46 @@ __global__ __launch_bounds__(64) void decode_block_kernel(DecodeArgs a, uint32_t
 }
 
 // The plan of a batch of images (DecodePlan): how many series are long and very long, how dense the long ones'
-// images are, and how dense every 64th image of the batch is.  All decompressors of the batch read it.
+// images are, how dense every 64th image of the batch is, and how much the very long sparse ones come to.  All
+// decompressors of the batch read it.
 __global__ __launch_bounds__(256) void plan_decode_kernel(DecodeArgs a, DecodePlan* plan)
 {
     // Every thread sums over its series, a workgroup adds its threads up through LDS, and one thread adds the six
     // sums to the plan: few atomics on the same six words however many series there are.
-    __shared__ unsigned long long part[4][6];
-    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ unsigned long long part[4][8];
+    unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long longest = 0;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.nseries; s += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t cap = a.pts.size(s);
         const bool is_long = cap >= a.tun.long_points, is_vlong = cap >= a.tun.vlong_points;
         const bool sampled = (s & 63u) == 0;
         const uint64_t nw = (is_long || sampled) ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
         if (is_long) { acc[0]++; acc[2] += nw; acc[3] += cap; }
-        if (is_vlong) acc[1]++;
+        if (is_vlong) {
+            acc[1]++;
+            if (nw * 64 < cap * a.tun.wg_dense_bits) { acc[6] += cap; longest = cap > longest ? cap : longest; }
+        }
         if (sampled) { acc[4] += nw; acc[5] += cap; }
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 7; i++) {
         const uint64_t t = wave_inclusive_scan64<false>(acc[i]);
         if (lane == 63) part[wave][i] = t;
     }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(longest >> 32), d, 64) << 32) |
+                                     (uint32_t)__shfl_xor((int)(uint32_t)longest, d, 64);
+        longest = o > longest ? o : longest;
+    }
+    if (lane == 0) part[wave][7] = longest;
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         const unsigned long long t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
         if (t) atomicAdd(reinterpret_cast<unsigned long long*>(plan) + threadIdx.x, t);
+    } else if (threadIdx.x == 7) {
+        unsigned long long t = part[0][7];
+        for (int w = 1; w < 4; w++) t = part[w][7] > t ? part[w][7] : t;
+        if (t) atomicMax(reinterpret_cast<unsigned long long*>(plan) + 7, t);
     }
 }
 

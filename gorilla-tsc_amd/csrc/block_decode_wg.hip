@@ -355,7 +355,7 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
 }
 
 // The chain of hops through the rows of a region that lies well inside the image (no field of a point that starts
-// in it can run off the image) and well before the caller's capacity, as one piece of assembly: the compiler's own
+// in it can run off the image; the capacity is the caller's to check afterwards), as one piece of assembly: the compiler's own
 // code for such a loop costs ten taken branches a row, and a lone wave pays a refill of its instruction buffer for
 // each.  Here a plain hop is a lane read, a bit set and a compare, and every second hop a taken branch.
 //
@@ -494,8 +494,8 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t
     return code;
 }
 
-// A region that lies well inside the image and ends well before the capacity is full (a region holds RPOS / 2 points
-// at most): nothing to check but the end marker and '10' codes before the first window.  Three ways through it:
+// A region that lies well inside the image: nothing to check but the end marker and '10' codes before the first
+// window.  (The capacity is the caller's to check afterwards: w.found_total.)  Three ways through it:
 // chase_rows() while the landing tables fit the window in force, a lane read per row -- the starts inside those rows
 // are found afterwards, lane r walking row r from where the chain entered it, all rows at once; walk_rows(), hop by
 // hop, through rows whose table says stop and wherever the tables were made for another window size; and strides:
@@ -750,7 +750,13 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                 uint32_t qn = 0;
                 if (!stop_prev) {
                     bool rest = true;
-                    if ((uint64_t)(k + 1) * RPOS + 256 < limit && cap - wk.found_total > QCAP + 64) qn = walk_region_fast(wk, L, k, lane, rest);
+                    if ((uint64_t)(k + 1) * RPOS + 256 < limit && wk.found_total < cap) {
+                        // (the fast walk does not count: if the region turns out to fill the capacity, it is walked
+                        // again by the form that looks at every point)
+                        const Walk before = wk;
+                        qn = walk_region_fast(wk, L, k, lane, rest);
+                        if (wk.found_total > cap) { wk = before; qn = 0; rest = true; }
+                    }
                     if (rest) {
                         GTSC_WG_WALK_COUNT(wk, tw_handover)
                         GTSC_WG_WALK_BEGIN(wk)

@@ -15,8 +15,8 @@ struct Tunables {
     uint64_t vlong_points = 16384;         // ... and from this many on "very long"
     uint64_t wave_decode_max = 12288;      // batches of up to this many long blocks: the wave-per-block decompressor takes them
     uint64_t wave_decode_max_dense = 2048; // the same when the long blocks' images come to more than dense_bits per point
-    uint64_t wg_decode_max = 256;          // batches of up to this many long blocks: the sparse ones get a workgroup each
-    uint64_t wg_decode_vlong_max = 512;    // batches of up to this many very long blocks: the sparse ones among those get a workgroup each
+    uint64_t wg_decode_max = 512;          // batches of up to this many long blocks: the sparse ones get a workgroup each
+    uint64_t wg_decode_vlong_max = 1024;   // very long blocks with sparse images get a workgroup each while together they come to no more than this many times the longest of them
     uint32_t wg_dense_bits = 40;           // a block counts as sparse below this many compressed bits per point of capacity
     uint32_t dense_bits = 64;              // see wave_decode_max_dense
     uint64_t sparse_encode_min = 57344;    // batches of at least this many long blocks of sparse streams: the lane-per-series compressor
@@ -57,7 +57,8 @@ struct DecodePlan {
     uint64_t nlong, nvlong;          // series with a capacity of at least long_points / vlong_points points
     uint64_t words_long, cap_long;   // the long ones' image words and capacities, summed
     uint64_t words_all, cap_all;     // the same over every 64th series of the batch
-    uint64_t pad[2];
+    uint64_t cap_vlong_sparse;       // capacities of the very long series with sparse images, summed ...
+    uint64_t cap_vlong_longest;      // ... and the largest of them
 };
 
 struct DecodeArgs {
@@ -98,7 +99,10 @@ __device__ __forceinline__ int block_owner(const DecodeArgs& a, uint64_t s)
     const DecodePlan& pl = *a.plan;
     const uint64_t nw = a.in_nwords ? a.in_nwords[s] : a.slots.size(s);
     const bool sparse = nw * 64 < cap * a.tun.wg_dense_bits;
-    if (sparse && (pl.nlong <= a.tun.wg_decode_max || (cap >= a.tun.vlong_points && pl.nvlong <= a.tun.wg_decode_vlong_max))) return OWNER_WG;
+    // (workgroups take their blocks a thousand or so at a time, waves all at once but four times slower: what counts is
+    // how many times the longest block the sparse very long ones come to together)
+    if (sparse && (pl.nlong <= a.tun.wg_decode_max ||
+                   (cap >= a.tun.vlong_points && pl.cap_vlong_sparse <= a.tun.wg_decode_vlong_max * pl.cap_vlong_longest))) return OWNER_WG;
     const bool dense_batch = pl.words_long * 64 > pl.cap_long * a.tun.dense_bits;
     return pl.nlong <= (dense_batch ? a.tun.wave_decode_max_dense : a.tun.wave_decode_max) ? OWNER_WAVE : OWNER_LANE;
 }
