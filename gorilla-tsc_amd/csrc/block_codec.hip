@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64) void decode_block_kernel(DecodeArgs a, uint32_t
     __shared__ BlockDecodeLds lds;
     const uint32_t lane = threadIdx.x;
     const uint64_t cand = blockIdx.x + (uint64_t)lane * gridDim.x;
-    const bool mine = lane < per_wave && cand < a.nseries && block_owner(a, cand) == OWNER_WAVE;
+    const bool mine = lane < per_wave && cand < a.nseries && block_owner<FMT>(a, cand) == OWNER_WAVE;
     uint64_t todo = lanes(mine);
     while (todo) {
         const uint32_t j = (uint32_t)__builtin_ctzll(todo);

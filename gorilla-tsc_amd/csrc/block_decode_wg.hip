@@ -972,7 +972,7 @@ __global__ __launch_bounds__(64 * NW) void decode_block_wg_kernel(DecodeArgs a, 
     __shared__ WgLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t cand = blockIdx.x + (uint64_t)lane * gridDim.x;
-    const bool mine = lane < per_group && cand < a.nseries && block_owner(a, cand) == OWNER_WG;
+    const bool mine = lane < per_group && cand < a.nseries && block_owner<FMT>(a, cand) == OWNER_WG;
     uint64_t todo = lanes(mine);   // (the same in every wave)
     while (todo) {
         const uint32_t j = (uint32_t)__builtin_ctzll(todo);

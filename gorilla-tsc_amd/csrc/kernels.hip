@@ -54,9 +54,10 @@ __global__ __launch_bounds__(256) void encode_direct_kernel(EncodeArgs a)
 }
 
 // true when series s is a wave's or a workgroup's: long, and the batch holds few enough long ones
+template <int FMT>
 __device__ __forceinline__ bool left_to_block_kernel(const DecodeArgs& a, uint64_t s)
 {
-    return block_owner(a, s) != OWNER_LANE;
+    return block_owner<FMT>(a, s) != OWNER_LANE;
 }
 
 template <int FMT, int PRED = PRED_LAST>
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void decode_direct_kernel(DecodeArgs a)
 {
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.nseries) return;
-    if (left_to_block_kernel(a, s)) return;
+    if (left_to_block_kernel<FMT>(a, s)) return;
     const uint64_t* in = a.words + a.slots.begin(s);
     uint64_t nw64 = a.in_nwords ? a.in_nwords[s] : a.slots.size(s);
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void de
         if (dense != (RING == 16)) return;
     }
     const uint64_t s = series_of_lane(blockIdx.x, lane, a.group_shift);
-    const bool valid = s < a.nseries && !left_to_block_kernel(a, s);
+    const bool valid = s < a.nseries && !left_to_block_kernel<FMT>(a, s);
     GTSC_DEC_STAMP_PROBE(valid)
     // The slot bounds are known before the image length is: the first 64 bytes of the slot are
     // requested right away and the length is looked at when they have arrived (one memory

@@ -86,12 +86,36 @@ struct DecodeArgs {
     uint32_t* dispatch;       // as in EncodeArgs
 };
 
+// Whether the timestamps of an image stray from their cadence early on: what the delta-of-deltas of its points 3 to 6
+// say (two of the four not zero).  Dense streams with such timestamps have points of ever-changing length, which
+// is what the wave-per-block decompressor is slowest at.
+template <int FMT>
+__device__ inline bool strays_early(const uint64_t* image, uint64_t nw64)
+{
+    const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
+    auto src = [image, nw](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
+    Decoder<FMT> d;
+    d.begin(nw, src);
+    int64_t t = 0, before = 0, delta = 0;
+    uint64_t v;
+    uint32_t strays = 0;
+    for (int i = 0; i < 6; i++) {
+        if (!d.next(t, v, src)) return false;
+        if (i >= 2 && t - before != delta) strays++;
+        delta = t - before;
+        before = t;
+    }
+    return strays >= 2;
+}
+
 // Which decompressor takes series s: the lane-per-series kernel (a lane), the wave-per-block kernel or the
 // workgroup-per-block kernel.  Sparse streams of few or very long blocks get a workgroup each (it follows the chain
-// of point starts two to three times faster where points are short or irregular); other long blocks get a wave each
-// while the batch holds few enough of them to leave the lanes of the lane-per-series kernel mostly idle -- fewer
-// when the images are dense, because irregular long points are what the wave-per-block kernel is slowest at.
+// of point starts several times faster where points are short or irregular), and so do dense ones of few blocks
+// whose timestamps stray from their cadence; other long blocks get a wave each while the batch holds few enough of
+// them to leave the lanes of the lane-per-series kernel mostly idle -- fewer when the images are dense, because
+// irregular long points are what the wave-per-block kernel is slowest at.
 constexpr int OWNER_LANE = 0, OWNER_WAVE = 1, OWNER_WG = 2;
+template <int FMT>
 __device__ __forceinline__ int block_owner(const DecodeArgs& a, uint64_t s)
 {
     const uint64_t cap = a.pts.size(s);
@@ -103,6 +127,10 @@ __device__ __forceinline__ int block_owner(const DecodeArgs& a, uint64_t s)
     // how many times the longest block the sparse very long ones come to together)
     if (sparse && (pl.nlong <= a.tun.wg_decode_max ||
                    (cap >= a.tun.vlong_points && pl.cap_vlong_sparse <= a.tun.wg_decode_vlong_max * pl.cap_vlong_longest))) return OWNER_WG;
+    if (!sparse && pl.nlong <= a.tun.wg_decode_max && a.tun.wg_decode_max != 0) {
+        const uint64_t ssz = a.slots.size(s);
+        if (strays_early<FMT>(a.words + a.slots.begin(s), nw < ssz ? nw : ssz)) return OWNER_WG;
+    }
     const bool dense_batch = pl.words_long * 64 > pl.cap_long * a.tun.dense_bits;
     return pl.nlong <= (dense_batch ? a.tun.wave_decode_max_dense : a.tun.wave_decode_max) ? OWNER_WAVE : OWNER_LANE;
 }

@@ -15,5 +15,8 @@ bash tools/profile.sh ${TAG}_gauge7200 --workload gauge --series 262144 --points
 for W in gauge random_walk; do
   timeout -k 10 300 python bench.py --workload $W --series 524288 --points 7200 --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $OUT/cfg3_share_524288x7200_$W.json 2>/dev/null || { echo "cfg3 share $W failed"; exit 1; }
 done
+timeout -k 10 200 python -u tools/block_class_time.py 100000 2>/dev/null | grep bits > $OUT/lone_block_classes.txt || { echo "block classes failed"; exit 1; }
+timeout -k 10 200 python -u tools/block_class_time.py 7200 2>/dev/null | grep bits > $OUT/lone_block_classes_7200.txt || { echo "block classes 7200 failed"; exit 1; }
+timeout -k 10 300 python tools/host_bench.py 2>/dev/null | grep "^{" > $OUT/host_bench.json || { echo "host bench failed"; exit 1; }
 { timeout -k 10 120 tools/ubench/decstore 120 && timeout -k 10 120 tools/ubench/decstore 128 && timeout -k 10 120 tools/ubench/encload 120 && timeout -k 10 120 tools/ubench/encload 128; } > $OUT/memory_patterns.txt 2>&1 || echo "ubench failed"
 echo evidence ok
