@@ -99,10 +99,13 @@ def test_dispatch_follows_from_the_batch_alone():
             out, off, nw, d_out, _ = check_encode_against_oracle(seasoned, hist, G.FMT_V2, O.V2, uniform=True)
             gpu_decode(seasoned, out, off, nw, hist.pt_off, G.FMT_V2, uniform_cap=hist.uniform_npoints(), d_words=d_out)
         skew = synth.skewed(total_points=150000, seed=3, pmin=10, pmax=30000)
+        strayed = synth.random_walk(S=40, P=3000, seed=16)   # dense values at scrape times a few ms off the cadence
+        strayed.ts = strayed.ts + np.random.default_rng(16).integers(-40, 41, strayed.ts.size)
         cases = [
             ("short uniform", synth.gauge_integer(S=3000, P=120, seed=5), True, G.DISPATCH_LANE_TILED, G.DISPATCH_WAVE | G.DISPATCH_WG | G.DISPATCH_PLAN),
             ("few long dense", synth.random_walk(S=40, P=3000, seed=6), True, G.DISPATCH_WAVE | G.DISPATCH_PLAN, 0),
             ("few long sparse", synth.gauge_integer(S=40, P=3000, seed=7), True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
+            ("few long dense, timestamps off the cadence", strayed, True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
             ("skewed lengths", skew, False, G.DISPATCH_PLAN | G.DISPATCH_WG | G.DISPATCH_WAVE | G.DISPATCH_LANE_TILED, 0),
         ]
         for name, b, uniform, must, must_not in cases:
