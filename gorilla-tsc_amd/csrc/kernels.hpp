@@ -16,7 +16,7 @@ struct Tunables {
     uint64_t wave_decode_max = 12288;      // batches of up to this many long blocks: the wave-per-block decompressor takes them
     uint64_t wave_decode_max_dense = 2048; // the same when the long blocks' images come to more than dense_bits per point
     uint64_t wg_decode_max = 512;          // batches of up to this many long blocks: the sparse ones get a workgroup each
-    uint64_t wg_decode_vlong_max = 1024;   // very long blocks with sparse images get a workgroup each while together they come to no more than this many times the longest of them
+    uint64_t wg_decode_vlong_max = 640;    // very long blocks with sparse images get a workgroup each while together they come to no more than this many times the longest of them
     uint32_t wg_dense_bits = 40;           // a block counts as sparse below this many compressed bits per point of capacity
     uint32_t dense_bits = 64;              // see wave_decode_max_dense
     uint64_t sparse_encode_min = 57344;    // batches of at least this many long blocks of sparse streams: the lane-per-series compressor

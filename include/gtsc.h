@@ -102,10 +102,10 @@ int gtsc_set_predictor(gtsc_ctx *ctx, int predictor, int table_size);
  *   GTSC_TUNE_LONG_POINTS (GTSC_LONG_POINTS, 1024): blocks of at least this many points ("long" blocks) may get a
  *     wavefront or a workgroup each instead of one lane of a wavefront that walks 64 blocks in lock step.
  *   GTSC_TUNE_VLONG_POINTS (GTSC_VLONG_POINTS, 16384): from this many points on a block is "very long".
- *   GTSC_TUNE_WG_DECODE_MAX (GTSC_WG_DECODE_MAX, 512) / GTSC_TUNE_WG_DECODE_VLONG_MAX (GTSC_WG_DECODE_VLONG_MAX, 1024):
+ *   GTSC_TUNE_WG_DECODE_MAX (GTSC_WG_DECODE_MAX, 512) / GTSC_TUNE_WG_DECODE_VLONG_MAX (GTSC_WG_DECODE_VLONG_MAX, 640):
  *     in batches of up to that many long blocks, the long blocks whose images are sparse are decompressed a
  *     workgroup per block -- and in any batch the very long ones with sparse images, while their capacities together
- *     come to no more than that many times the largest of them (1,024 blocks of equal length; more of mixed lengths);
+ *     come to no more than that many times the largest of them (640 blocks of equal length; more of mixed lengths);
  *     GTSC_TUNE_WG_DENSE_BITS (GTSC_WG_DENSE_BITS, 40): sparse = fewer compressed bits per point of capacity than this.
  *   GTSC_TUNE_WAVE_DECODE_MAX (GTSC_LONG_DECODE_MAX, 12288): in batches of up to that many long blocks the other
  *     long blocks are decompressed a wavefront per block; GTSC_TUNE_WAVE_DECODE_MAX_DENSE (GTSC_LONG_DECODE_MAX_DENSE,
