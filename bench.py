@@ -362,6 +362,8 @@ def main():
                 raise
         bits_per_point = 64.0 * int(nw.sum()) / max(S * P, 1)
         tun = {"decode_ring": 16 if bits_per_point > 40 else 8, "sparse_hint": 1 if bits_per_point <= 16 else 0}
+        if os.environ.get("GTSC_BENCH_RING"):   # (measurements: what a caller who leaves the ring to the device gets)
+            tun["decode_ring"] = int(os.environ["GTSC_BENCH_RING"])
         ctx.set_decode_ring(tun["decode_ring"])
         ctx.set_tunable(G.TUNE_SPARSE_HINT, tun["sparse_hint"])
         with torch.cuda.stream(stream):

@@ -22,7 +22,7 @@ struct Tunables {
     uint64_t sparse_encode_min = 57344;    // batches of at least this many long blocks of sparse streams: the lane-per-series compressor
     uint64_t coop_encode_max = 384;        // batches of up to this many long blocks: the compressor gives each a workgroup
     uint32_t sparse_hint = 0;              // 1: the streams to compress are sparse (a few bits per point)
-    uint32_t decode_ring = 8;              // input rings of the lane-per-series decompressor: 8 or 16 words; 0 = by the batch's density
+    uint32_t decode_ring = 0;              // input rings of the lane-per-series decompressor: 8 or 16 words; 0 = by the batch's density, on the device
     uint32_t run_skip = 1;                 // 0: the lane-per-series kernels keep to their lock-step loops
     uint32_t direct = 0;                   // 1: the plain lane-per-series kernels only
 };

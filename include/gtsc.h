@@ -116,10 +116,11 @@ int gtsc_set_predictor(gtsc_ctx *ctx, int predictor, int table_size);
  *   GTSC_TUNE_SPARSE_HINT (GTSC_SPARSE_HINT, 0): 1 tells the compressor that the streams are sparse (a few bits per
  *     point: mostly unchanged values at a regular interval); batches of at least GTSC_TUNE_SPARSE_ENCODE_MIN
  *     (GTSC_SPARSE_TILED_MIN, 57344) long blocks are then compressed a lane per block, which skips runs of such points.
- *   GTSC_TUNE_DECODE_RING (GTSC_RING, 8): the lane-per-series decompressor exists with input rings of 8 words per
- *     series (fastest on streams of a few bits per point) and of 16 words (3-10 % faster on streams of tens of bits
+ *   GTSC_TUNE_DECODE_RING (GTSC_RING, 0): the lane-per-series decompressor exists with input rings of 8 words per
+ *     series (fastest on streams of a few bits per point) and of 16 words (15-30 % faster on streams of tens of bits
  *     per point); 0 = the batch's density decides, on the device: both forms are launched and one of them returns
- *     at once (about 10 us per call).  gtsc_decode_host knows each chunk's density beforehand and treats 0 as "by density" at no cost.
+ *     at once (about 20 us per call: 3-5 % of a million short series; a caller who knows its streams pins 8 or 16).
+ *     gtsc_decode_host knows each chunk's density beforehand and treats 0 as "by density" at no cost.
  *   GTSC_TUNE_RUN_SKIP (GTSC_RUN_SKIP, 1): 0 keeps the lane-per-series kernels on their lock-step loops.
  *   GTSC_TUNE_DIRECT_KERNELS (GTSC_DIRECT, 0): 1 selects the plain lane-per-series kernels (no LDS staging) for everything.
  *

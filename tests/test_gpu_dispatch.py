@@ -102,7 +102,7 @@ def test_dispatch_follows_from_the_batch_alone():
         strayed = synth.random_walk(S=40, P=3000, seed=16)   # dense values at scrape times a few ms off the cadence
         strayed.ts = strayed.ts + np.random.default_rng(16).integers(-40, 41, strayed.ts.size)
         cases = [
-            ("short uniform", synth.gauge_integer(S=3000, P=120, seed=5), True, G.DISPATCH_LANE_TILED, G.DISPATCH_WAVE | G.DISPATCH_WG | G.DISPATCH_PLAN),
+            ("short uniform", synth.gauge_integer(S=3000, P=120, seed=5), True, G.DISPATCH_LANE_TILED, G.DISPATCH_WAVE | G.DISPATCH_WG),
             ("few long dense", synth.random_walk(S=40, P=3000, seed=6), True, G.DISPATCH_WAVE | G.DISPATCH_PLAN, 0),
             ("few long sparse", synth.gauge_integer(S=40, P=3000, seed=7), True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
             ("few long dense, timestamps off the cadence", strayed, True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
