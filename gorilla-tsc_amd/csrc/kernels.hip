@@ -655,8 +655,9 @@ constexpr uint32_t DCH = CH;                      // slots per row per chunk
 // the words further ahead of the parser than 8 slots allow: under the decoder's own store traffic
 // a top-up takes longer than the two points between request and landing, and every landing is
 // a wait.  With 16 slots (7 waves per CU) a landing is put off until a lane is down to five unread
-// words or the load is five checks old, which by then has arrived.  The library picks the
-// form from the density it has seen (DecodeArgs::deep_ring).
+// words or the load is five checks old, which by then has arrived.  Which form runs is the
+// caller's choice (Tunables::decode_ring) or, left open, follows from the density of the batch as
+// the plan kernel measured it (DecodeArgs::ring_by_plan: both forms are launched, one returns).
 constexpr uint32_t IN_NEVER = 0xFFFFFFFFu;        // "limit" of a lane with nothing left to load
 
 // The decoder's timestamp tile holds only the low half of each timestamp (4 bytes per slot):
