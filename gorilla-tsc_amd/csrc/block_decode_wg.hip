@@ -738,12 +738,13 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
         GTSC_WG_STAMP_DECL
         bool stop_prev = false;       // the walker stopped in the tick before: this one only emits
         uint32_t qprev = 0;           // points the walker queued in the tick before
+        // what the walker reported at the end of the tick before (read by every wave between that tick's barriers, so
+        // that all of them make this tick's tables for the same window size)
+        uint32_t wnb_seen = 0;
+        bool want_seen = true;
         for (uint32_t k = 0;; k++) {
             const uint32_t slot = k & 1u, pslot = slot ^ 1u;
             uint64_t s_loc[MB], x_loc[MB];
-            // (what the walker wrote before the barrier that ended the tick before)
-            const uint32_t wnb_seen = lds_peek(&L.curwnb);
-            const bool want_seen = lds_peek(&L.want_tables) != 0;
             // ---- the walker in region k; the others classify region k + 1 and parse what was queued in region k - 1
             GTSC_WG_TICK(tk_other)
             if (wave == 0) {
@@ -839,12 +840,18 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
             if (stop_now) clean_end = lds_peek(&L.clean) != 0;
             // ---- the walker has changed its window size under way: the landing tables of region k + 1 once more, four
             // rows per wave
-            if (!stop_prev && !stop_now) {
+            {
                 const uint32_t wnb_now = lds_peek(&L.curwnb);
-                const bool again = want_seen && wnb_now != wnb_seen;
-                if (again) make_landing_tables(L, k + 1, 4 * wave, wnb_now, lane);
-                if (tid == 0) L.landwnb[pslot] = want_seen ? wnb_now : 0xFFFFFFFFu;
-                if (again && !qprev) wg_barrier();   // (with points to emit, the barrier below stands between the tables and their use)
+                const bool want_now = lds_peek(&L.want_tables) != 0;
+                if (!stop_prev && !stop_now) {
+                    if (want_seen && wnb_now != wnb_seen) make_landing_tables(L, k + 1, 4 * wave, wnb_now, lane);
+                    if (tid == 0) L.landwnb[pslot] = want_seen ? wnb_now : 0xFFFFFFFFu;
+                }
+                wnb_seen = wnb_now;
+                want_seen = want_now;
+                // Without points to emit there is no second barrier below: one here, so that no wave is still reading what
+                // the walker reported (or making tables) when the walker goes on into the next region.
+                if (!qprev) wg_barrier();
             }
             uint32_t kbv = 0xFFFFFFFFu;
             const uint32_t nb = (qprev + 63) / 64;

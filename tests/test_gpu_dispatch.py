@@ -172,6 +172,32 @@ def test_tunables_move_blocks_between_kernels_not_results():
         ctx.close()
 
 
+@pytest.mark.parametrize("kernel", ["by the batch", "workgroups", "waves", "lanes"])
+def test_long_blocks_whose_character_changes_along_the_block(kernel):
+    """A slice of tools/stress_long_blocks.py: a few blocks of 1,000 to 60,000 points made of stretches of different
+    kinds (constant, gauge, counter, random walk, random bits; regular, jittered and wild timestamps; timestamps that
+    pass through zero), both formats, capacities exact, short and generous, images cut short, with zeroed tails and
+    flipped bits -- with the kernels the batch gets by itself and with every long block sent to each decompressor in
+    turn.  (The whole sweep has been run for 16,000 cases through the workgroup-per-block kernel and 7,000 and 6,000
+    through the other two.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stress_long_blocks as SL
+    tunables = {"by the batch": {},
+                "workgroups": {G.TUNE_WG_DECODE_MAX: HUGE, G.TUNE_WG_DENSE_BITS: 1 << 30},
+                "waves": {G.TUNE_WG_DECODE_MAX: 0, G.TUNE_WG_DECODE_VLONG_MAX: 0, G.TUNE_WAVE_DECODE_MAX: HUGE, G.TUNE_WAVE_DECODE_MAX_DENSE: HUGE},
+                "lanes": {G.TUNE_WG_DECODE_MAX: 0, G.TUNE_WG_DECODE_VLONG_MAX: 0, G.TUNE_WAVE_DECODE_MAX: 0, G.TUNE_WAVE_DECODE_MAX_DENSE: 0}}[kernel]
+    must = {"by the batch": 0, "workgroups": G.DISPATCH_WG, "waves": G.DISPATCH_WAVE, "lanes": G.DISPATCH_LANE_TILED}[kernel]
+    ctx = G.Context(0)
+    try:
+        for which, value in tunables.items():
+            ctx.set_tunable(which, value)
+        for seed in (13, 77, 5003, 5100):   # (13: the batch on which a race between the walker and the table makers showed)
+            _, _, seen = SL.run_case(ctx, seed)
+            assert seen & must == must
+    finally:
+        ctx.close()
+
+
 def test_sparse_hint_sends_many_long_blocks_to_the_lane_per_series_compressor():
     """GTSC_TUNE_SPARSE_HINT (with the block count from which it applies set to zero): the same batch compressed a
     wavefront per block and a lane per block gives the oracle's words both ways, in both formats."""
