@@ -103,7 +103,8 @@ struct WgLds {
     uint32_t kb[2];                // first batch that decoded a timestamp of zero (or none)
     uint32_t anydd[2];             // some point of the region changed the interval
     uint32_t stop, clean;          // the walker met the end of the stream or something for the serial decoder
-    uint32_t endrel, endwin;       // where the last queued point of the region ends, and the window after it
+    uint32_t endrel[2], endwin[2]; // where the last queued point of a region ends, and the window after it (by the region's parity:
+                                   // a wave may still be reading one region's while the next one's is written)
     uint64_t sbits[RW];            // the walker's own: starts found by strides in the region under way (bit l of word r: position 64 r + l)
     uint8_t land[2 * RPOS];        // landing tables: land[p % (2 RPOS)] = where the chain that enters p's row at p leaves the row
     uint32_t landwnb[2];           // the window size (significant bits) the tables of a region were made for
@@ -824,8 +825,8 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                         if (lane == m - 1) {
                             L.aggD[b] = dsum; L.aggS[b] = ssum; L.aggX[b] = xsum;
                             if (b * 64 + m == qprev) {   // the region's last point: where it ends, and the window after it
-                                L.endrel = rel + pq.o3;
-                                L.endwin = pq.nbits | (((uint32_t)pq.trail & 127u) << 7);
+                                L.endrel[pslot] = rel + pq.o3;
+                                L.endwin[pslot] = pq.nbits | (((uint32_t)pq.trail & 127u) << 7);
                             }
                         }
                     }
@@ -917,8 +918,8 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                     stored_ts = stored_ts + read_lane(tinc, nb - 1);
                     val = val ^ read_lane(xinc, nb - 1);
                     n += qprev;
-                    pos = g + lds_peek(&L.endrel);
-                    win = lds_peek(&L.endwin);
+                    pos = g + lds_peek(&L.endrel[pslot]);
+                    win = lds_peek(&L.endwin[pslot]);
                 } else {
                     // up to the batch that met a zero timestamp; the serial decoder has the rest
                     stored_delta = read_lane(delta_in, kbv);
