@@ -201,6 +201,12 @@ __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p)
 {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
+__device__ __forceinline__ uint64_t lds_peek64(const uint64_t* p)
+{
+    const uint64_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 // All waves of the workgroup have carried out their LDS accesses up to here.  (Not __syncthreads(): that
 // would also wait for global memory, and the stores of decoded points are meant to stay in flight.)
 __device__ __forceinline__ void wg_barrier()
@@ -226,6 +232,7 @@ struct Walk {
     uint32_t backoff;        // rows to the stride attempt after the next one that fails
     bool last_known;         // last_len / last_t1 say what the last point was
     bool want_tables;        // the last region was not one that strides carried
+    bool allow_pause, pause; // the walker may ask for / asks for the pipeline to stop here so that stride_phase() takes over
     GTSC_WG_WALK_DECL
 };
 
@@ -656,9 +663,147 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     const uint32_t found = read_lane(incl, 63);
     w.found_total += found;
     w.want_tables = 4 * stride_points < 3 * found || found == 0;
+    w.pause = w.allow_pause && !handover && found >= 64 && !w.want_tables;
 
     GTSC_WG_WALK_TICK(w, tw_queue)
     return found;
+}
+
+// The serial decoder, set to go on from a committed state (the point after the last one handed to the output).
+template <int FMT, class Src>
+__device__ __forceinline__ void decoder_from_state(Decoder<FMT>& d, uint32_t nw, Src& src, uint64_t pos, uint64_t stored_delta,
+                                                   uint64_t stored_ts, uint64_t val, uint32_t win)
+{
+    const uint32_t nbits = win & 127u;
+    const int32_t trail = sext7(win >> 7);
+    d.nwords = nw;
+    d.widx = (uint32_t)(pos >> 6); d.off = (uint32_t)pos & 63u;
+    d.r0 = src(d.widx); d.r1 = src(d.widx + 1); d.r2 = src(d.widx + 2); d.r3 = src(d.widx + 3);
+    d.st = 0;
+    d.block_ts = (int64_t)src(0); d.stored_delta = (int64_t)stored_delta; d.stored_ts = stored_ts; d.val = val; d.pred_last = 0;
+    d.lead = nbits ? (uint32_t)(64 - (int32_t)nbits - trail) : NO_WINDOW;
+    d.trail = trail;
+}
+
+// Streams of plain points of equal length -- regular interval ('0'), changed value inside the window in force ('10' and
+// the window's bits): `(double) i` of the reference's own benchmark (G/benchmark/EncodingBenchmark.java:60-69), counters
+// that move at every sample.  Where such a run begins nothing is serial any more: point j starts j lengths on, every
+// thread checks one candidate (the three control bits, the image's end, the capacity, a timestamp of zero), the first
+// that fails ends the run, and the values before it are a prefix XOR of the payloads, the timestamps a multiple of the
+// interval.  Before the pipeline of decode_block_wg() starts, the block is taken as far as that goes: runs of up to
+// 1,024 points a round (the first round of a run by wave 0 alone, 64 candidates: most blocks are not of this kind and
+// should not pay for more), and between runs the point that ended one is decoded by one lane with the serial decoder
+// (a '11' code that declares the next window, as a rule).  The phase ends when the runs stay short, and the pipeline
+// goes on from the state it leaves (or the serial decoder, after a decoded timestamp of zero).
+// `proven`: the pipeline has seen the stream go by strides (it pauses to let this phase take over): short runs are
+// put up with as long as the last few come to something.  Returns the points decoded by runs.
+template <int FMT, uint32_t NW>
+__device__ __forceinline__ uint32_t stride_phase(const DecodeArgs& a, const uint64_t* image, uint32_t nw, uint64_t p0, uint32_t cap, uint64_t limit,
+                                                 WgLds& L, uint32_t tid, uint64_t& pos, uint32_t& n, uint64_t& stored_delta,
+                                                 uint64_t& stored_ts, uint64_t& val, uint32_t& win, bool& serial, bool proven)
+{
+    constexpr uint32_t NT = NW * 64;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    auto src = [&](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
+    uint32_t runs = 0, empty_runs = 0, accepted = 0, parity = 0;
+    uint32_t recent = 1024;   // about eight times the length of the last few runs
+    for (;;) {
+        // ---- a run from `pos` on
+        const uint32_t wnb = win & 127u;
+        uint32_t run = 0;
+        if (wnb != 0) {
+            const uint32_t len = 3u + wnb, trail = (uint32_t)sext7(win >> 7) & 63u;
+            for (uint32_t round = 0;; round++, parity ^= 1u) {
+                const uint32_t width = round == 0 ? 64u : NT;
+                const bool mine = round != 0 || wave == 0;
+                const uint32_t j = round == 0 ? lane : tid;
+                uint64_t x = 0, scan = 0;
+                if (mine) {
+                    const uint64_t p = pos + (uint64_t)j * len;
+                    const bool inside = p + 67 + 128 < limit && n + j < cap;   // (no field of the point can run off the image)
+                    const uint32_t kw = inside ? (uint32_t)(p >> 6) : 0u, o = (uint32_t)p & 63u;
+                    const uint64_t w0 = image[kw], w1 = image[kw + 1], w2 = image[kw + 2];
+                    const uint64_t hi = WindowDecoder<FMT>::window(w0, w1, o), lo = WindowDecoder<FMT>::window(w1, w2, o);
+                    const uint64_t pay = ((hi << 3) | (lo >> 61)) >> (64u - wnb);
+                    const uint64_t tsj = stored_ts + (uint64_t)(j + 1) * stored_delta;
+                    const bool ok = inside && (hi >> 61) == 2u && tsj != 0;
+                    const uint64_t bad = lanes(!ok);
+                    const uint32_t fb = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                    x = lane < fb ? pay << trail : 0ull;
+                    scan = wave_inclusive_scan64<true>(x);
+                    if (lane == 63) { L.aggD[parity * 16 + wave] = fb; L.aggX[parity * 16 + wave] = scan; }
+                }
+                wg_barrier();
+                // the first wave with a candidate that failed, and what the waves before this one add up to
+                const uint32_t waves_in = round == 0 ? 1u : NW;
+                const uint64_t fbw = lane < waves_in ? L.aggD[parity * 16 + lane] : 64ull;
+                const uint64_t tot = lane < waves_in ? L.aggX[parity * 16 + lane] : 0ull;
+                const uint64_t short_m = lanes(fbw < 64);
+                const uint32_t fw = short_m ? (uint32_t)__builtin_ctzll(short_m) : waves_in;   // (waves_in: none failed)
+                const uint32_t got = fw < waves_in ? fw * 64 + (uint32_t)read_lane((uint32_t)fbw, fw) : width;
+                const uint64_t before = read_lane(wave_inclusive_scan64<true>(lane < wave ? tot : 0ull), 63);
+                const uint64_t all = read_lane(wave_inclusive_scan64<true>(lane <= fw ? tot : 0ull), 63);
+                if (mine && j < got) {
+                    __builtin_nontemporal_store((int64_t)(stored_ts + (uint64_t)(j + 1) * stored_delta), a.ts + p0 + n + j);
+                    __builtin_nontemporal_store(val ^ before ^ scan, a.val + p0 + n + j);
+                }
+                n += got;
+                pos += (uint64_t)got * len;
+                stored_ts += (uint64_t)got * stored_delta;
+                val ^= all;
+                run += got;
+                if (got < width) break;
+            }
+            parity ^= 1u;
+        }
+        runs++;
+        accepted += run;
+        empty_runs = run ? 0u : empty_runs + 1u;
+        recent = recent - (recent >> 3) + (run < 1024 ? run : 1024u);
+        // most blocks are not of this kind: three points in a row that start no run, or runs that do not grow (at a
+        // block's start) / that have become short (later on)
+        if (empty_runs >= 3) break;
+        if (proven ? recent < 128 : (runs >= 4 && accepted < (1u << (runs < 21 ? runs - 1 : 20)))) break;
+        if (n >= cap || pos + 512 >= limit) break;
+        // ---- the point that ended the run, by the serial decoder
+        if (tid == 0) {
+            Decoder<FMT> d;
+            decoder_from_state(d, nw, src, pos, stored_delta, stored_ts, val, win);
+            int64_t t; uint64_t v;
+            uint64_t flag = 1;   // 1: no point (end of stream or something wrong: the pipeline's checked walk has it)
+            if (d.next(t, v, src)) {
+                a.ts[p0 + n] = t; a.val[p0 + n] = v;
+                const uint32_t nb = d.lead == NO_WINDOW ? 0u : (uint32_t)(64 - (int32_t)d.lead - d.trail);
+                L.aggS[0] = (uint64_t)d.widx * 64 + d.off;
+                L.aggS[1] = (uint64_t)d.stored_delta;
+                L.aggS[2] = d.stored_ts;
+                L.aggS[3] = d.val;
+                L.aggS[4] = nb | (((uint32_t)d.trail & 127u) << 7);
+                flag = d.stored_ts == 0 ? 2 : 0;   // 2: a timestamp of zero: the serial decoder has the rest
+            }
+            L.aggS[5] = flag;
+        }
+        wg_barrier();
+        const uint64_t flag = lds_peek64(&L.aggS[5]);
+        if (flag != 1) {
+            pos = lds_peek64(&L.aggS[0]); stored_delta = lds_peek64(&L.aggS[1]); stored_ts = lds_peek64(&L.aggS[2]);
+            val = lds_peek64(&L.aggS[3]); win = (uint32_t)lds_peek64(&L.aggS[4]);
+            n++;
+        }
+        wg_barrier();   // (the next serial point overwrites what was just read)
+        if (flag == 2) serial = true;
+        if (flag != 0) break;
+    }
+    // (every thread holds the same state; saying so keeps it in scalar registers from here on)
+    auto uniform64 = [](uint64_t v) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    pos = uniform64(pos); stored_delta = uniform64(stored_delta); stored_ts = uniform64(stored_ts); val = uniform64(val);
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    win = (uint32_t)__builtin_amdgcn_readfirstlane((int)win);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)accepted);
 }
 
 // Decompresses block `s` with the whole workgroup of NW waves.
@@ -706,10 +851,22 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
     }
     bool clean_end = finished;
 
+    // The block goes through two kinds of phases in turn: runs of plain points of equal length as far as they go
+    // (stride_phase()), then the pipeline -- until the stream ends, or the walker sees it go by strides again and pauses.
+    bool allow_pause = true, proven = false;
+    for (;;) {
+    if (!finished && !serial) {
+        const uint32_t by_runs = stride_phase<FMT, NW>(a, image, nw, p0, cap, limit, L, tid, pos, n, stored_delta, stored_ts, val, win, serial, proven);
+        if (proven && by_runs < 512) allow_pause = false;   // (a pause that bought this little is not worth another)
+    }
+    bool paused = false;
+
     if (!finished && !serial) {
         auto word = [&](uint32_t w) -> uint64_t { return w < nw ? image[w] : 0ull; };
-        // ---- prologue: image words [0, 2 RW], the hop words of region 0
-        for (uint32_t w = tid; w < 2 * RW + 1; w += NT) L.ring[w] = word(w);
+        // ---- prologue: the pipeline starts in the region that holds `pos`: its image words and those of the region
+        // after it, its hop words and landing tables
+        const uint32_t k0 = (uint32_t)(pos / RPOS);
+        for (uint32_t w = tid; w < 2 * RW + 1; w += NT) L.ring[(k0 * RW + w) & (RINGW - 1)] = word(k0 * RW + w);
         if (tid == 0) { L.stop = 0; L.clean = 0; L.qcount[0] = 0; L.qcount[1] = 0; }
         if (tid < RW) L.sbits[tid] = 0;
         wg_barrier();
@@ -728,22 +885,22 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                 *reinterpret_cast<uint4*>(&L.hopw[((uint32_t)P & (2 * RPOS - 1))]) = h;
             }
         };
-        classify_region(0, tid, NT);
+        classify_region(k0, tid, NT);
         // (a wave classifies whole rows -- four positions per lane, 256 per pass: the tables of its rows are its own work)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        make_landing_tables(L, 0, 4 * wave, 0u, lane);
-        if (tid == 0) { L.landwnb[0] = 0; L.landwnb[1] = 0xFFFFFFFFu; L.curwnb = 0; L.want_tables = 1; }
+        make_landing_tables(L, k0, 4 * wave, win & 127u, lane);
+        if (tid == 0) { L.landwnb[k0 & 1u] = win & 127u; L.landwnb[(k0 & 1u) ^ 1u] = 0xFFFFFFFFu; L.curwnb = win & 127u; L.want_tables = 1; }
         wg_barrier();
 
-        Walk wk{pos, 0u, 0u, 0u, false, 0u, 1u, false, false, 8u, true, true};
+        Walk wk{pos, win & 127u, win >> 7, 0u, false, 0u, n, false, false, 8u, true, true, allow_pause, false};
         GTSC_WG_STAMP_DECL
         bool stop_prev = false;       // the walker stopped in the tick before: this one only emits
         uint32_t qprev = 0;           // points the walker queued in the tick before
         // what the walker reported at the end of the tick before (read by every wave between that tick's barriers, so
         // that all of them make this tick's tables for the same window size)
-        uint32_t wnb_seen = 0;
+        uint32_t wnb_seen = win & 127u;
         bool want_seen = true;
-        for (uint32_t k = 0;; k++) {
+        for (uint32_t k = k0;; k++) {
             const uint32_t slot = k & 1u, pslot = slot ^ 1u;
             uint64_t s_loc[MB], x_loc[MB];
             // ---- the walker in region k; the others classify region k + 1 and parse what was queued in region k - 1
@@ -768,7 +925,7 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
                 }
                 if (lane == 0) {
                     L.qcount[slot] = qn;
-                    L.stop = wk.stop ? 1u : 0u;
+                    L.stop = wk.stop ? 1u : wk.pause ? 2u : 0u;
                     L.clean = wk.clean_end ? 1u : 0u;
                     L.curwnb = wk.wnb;
                     L.want_tables = wk.want_tables ? 1u : 0u;
@@ -837,8 +994,10 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
             wg_barrier();
             GTSC_WG_TICK(tk_b1)
             const uint32_t qnow = lds_peek(&L.qcount[slot]);
-            const bool stop_now = lds_peek(&L.stop) != 0;
-            if (stop_now) clean_end = lds_peek(&L.clean) != 0;
+            const uint32_t stop_code = lds_peek(&L.stop);
+            const bool stop_now = stop_code != 0;
+            if (stop_code == 1) clean_end = lds_peek(&L.clean) != 0;
+            if (stop_code == 2) paused = true;
             // ---- the walker has changed its window size under way: the landing tables of region k + 1 once more, four
             // rows per wave
             {
@@ -940,25 +1099,19 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
         GTSC_WG_STAMP_PRINT
         GTSC_WG_WALK_PRINT(wk)
     }
+    // (paused: everything the walker queued has been handed to the output, the committed state is where the runs go on)
+    if (!paused || serial || finished) break;
+    proven = true;
+    wg_barrier();   // (the pipeline's last reads of LDS before the run phase reuses it)
+    }
     uint32_t st = 0;
     if (!clean_end || serial) {
         // ---- the serial decoder, one lane, from the committed state (exact order of the reference's checks)
         if (tid == 0) {
             auto src = [&](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
             Decoder<FMT> d;
-            if (nw < 4 || pos < 64) {
-                d.begin(nw, src);
-            } else {
-                const uint32_t nbits = win & 127u;
-                const int32_t trail = sext7(win >> 7);
-                d.nwords = nw;
-                d.widx = (uint32_t)(pos >> 6); d.off = (uint32_t)pos & 63u;
-                d.r0 = src(d.widx); d.r1 = src(d.widx + 1); d.r2 = src(d.widx + 2); d.r3 = src(d.widx + 3);
-                d.st = 0;
-                d.block_ts = (int64_t)src(0); d.stored_delta = (int64_t)stored_delta; d.stored_ts = stored_ts; d.val = val; d.pred_last = 0;
-                d.lead = nbits ? (uint32_t)(64 - (int32_t)nbits - trail) : NO_WINDOW;
-                d.trail = trail;
-            }
+            if (nw < 4 || pos < 64) d.begin(nw, src);
+            else decoder_from_state(d, nw, src, pos, stored_delta, stored_ts, val, win);
             int64_t t; uint64_t v;
             while (d.next(t, v, src)) {
                 if (n < cap) { a.ts[p0 + n] = t; a.val[p0 + n] = v; } else st = ST_OVERFLOW;

@@ -106,6 +106,7 @@ def test_dispatch_follows_from_the_batch_alone():
             ("few long dense", synth.random_walk(S=40, P=3000, seed=6), True, G.DISPATCH_WAVE | G.DISPATCH_PLAN, 0),
             ("few long sparse", synth.gauge_integer(S=40, P=3000, seed=7), True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
             ("few long dense, timestamps off the cadence", strayed, True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
+            ("equal-sized points, window changes at powers of two", synth.readme_workload(S=3, P=50000), True, G.DISPATCH_WG | G.DISPATCH_PLAN, 0),
             ("skewed lengths", skew, False, G.DISPATCH_PLAN | G.DISPATCH_WG | G.DISPATCH_WAVE | G.DISPATCH_LANE_TILED, 0),
         ]
         for name, b, uniform, must, must_not in cases:
