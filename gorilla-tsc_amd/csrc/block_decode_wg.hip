@@ -709,10 +709,62 @@ __device__ __forceinline__ uint32_t stride_phase(const DecodeArgs& a, const uint
     uint32_t runs = 0, empty_runs = 0, accepted = 0, parity = 0;
     uint32_t recent = 1024;   // about eight times the length of the last few runs
     for (;;) {
-        // ---- a run from `pos` on
+        // ---- a run from `pos` on: unchanged points at a regular interval first ('00' each: as many as half the zero
+        // bits ahead), every thread looking at one image word a round
         const uint32_t wnb = win & 127u;
         uint32_t run = 0;
-        if (wnb != 0) {
+        const uint64_t inside_end = limit > 195 ? limit - 195 : 0;   // a point must start before this (as `inside` below)
+        if (pos < inside_end && n < cap) {
+            const uint32_t kw = (uint32_t)(pos >> 6), o = (uint32_t)pos & 63u;
+            const uint64_t first = image[kw] << o;
+            uint64_t zeros = first ? clz64(first) : 64u - o;
+            if (!first) {
+                // the rest of the word is zero: the words after it, NT a round, up to the first that is not
+                const uint32_t wend = (uint32_t)(inside_end >> 6) + 1;   // (< nw)
+                for (uint32_t wbase = kw + 1; wbase < wend; wbase += NT, parity ^= 1u) {
+                    const uint32_t w = wbase + tid;
+                    const uint64_t x = w < wend ? image[w] : 1ull;
+                    const uint64_t nz = lanes(x != 0);
+                    const uint32_t fl = nz ? (uint32_t)__builtin_ctzll(nz) : 64u;
+                    if (lane == 0) L.aggD[parity * 16 + wave] = fl < 64 ? (uint64_t)(wave * 64 + fl) * 64 + clz64(read_lane(x, fl)) : 64ull * NT;
+                    wg_barrier();
+                    const uint64_t mine = lane < NW ? L.aggD[parity * 16 + lane] : ~0ull;
+                    // (the first wave that met a word other than zero says how many zero bits lie before its first one)
+                    const uint64_t stopped = lanes(mine < 64ull * NT);
+                    const uint64_t more = stopped ? read_lane(mine, (uint32_t)__builtin_ctzll(stopped)) : 64ull * NT;
+                    zeros += more;
+                    if (more < 64ull * NT) break;
+                }
+                parity ^= 1u;
+            }
+            uint64_t count = zeros >> 1;
+            const uint64_t room = (inside_end - pos + 1) >> 1;
+            count = count < room ? count : room;
+            count = count < cap - n ? count : cap - n;
+            // a timestamp of exactly zero ends the run before it (the point after it is read as a "first" one): the
+            // smallest m > 0 with stored_ts + m * stored_delta == 0 (mod 2^64), if any
+            if (stored_delta != 0 && count) {
+                const uint32_t v = (uint32_t)__builtin_ctzll(stored_delta);
+                const uint64_t odd = stored_delta >> v, target = 0ull - stored_ts;
+                if ((target & ((1ull << v) - 1ull)) == 0) {
+                    uint64_t inv = odd;   // inverse of an odd number mod 2^64: three bits right to begin with, doubled five times
+                    for (int i = 0; i < 5; i++) inv *= 2ull - odd * inv;
+                    uint64_t m = (target >> v) * inv;
+                    if (v) m &= (1ull << (64u - v)) - 1ull;
+                    if (m != 0 && m - 1 < count) count = m - 1;
+                }
+            }
+            for (uint64_t j = tid; j < count; j += NT) {
+                __builtin_nontemporal_store((int64_t)(stored_ts + (j + 1) * stored_delta), a.ts + p0 + n + j);
+                __builtin_nontemporal_store(val, a.val + p0 + n + j);
+            }
+            run = (uint32_t)count;
+            n += run;
+            pos += 2ull * count;
+            stored_ts += count * stored_delta;
+        }
+        // ---- then changed values inside the window in force ('0', '10', the window's bits)
+        if (run == 0 && wnb != 0) {
             const uint32_t len = 3u + wnb, trail = (uint32_t)sext7(win >> 7) & 63u;
             for (uint32_t round = 0;; round++, parity ^= 1u) {
                 const uint32_t width = round == 0 ? 64u : NT;
@@ -761,10 +813,10 @@ __device__ __forceinline__ uint32_t stride_phase(const DecodeArgs& a, const uint
         accepted += run;
         empty_runs = run ? 0u : empty_runs + 1u;
         recent = recent - (recent >> 3) + (run < 1024 ? run : 1024u);
-        // most blocks are not of this kind: three points in a row that start no run, or runs that do not grow (at a
-        // block's start) / that have become short (later on)
+        // most blocks are not of this kind: three points in a row that start no run, a short run (at a block's start:
+        // one look is all such a block should pay for) or runs that have become short (later on)
         if (empty_runs >= 3) break;
-        if (proven ? recent < 128 : (runs >= 4 && accepted < (1u << (runs < 21 ? runs - 1 : 20)))) break;
+        if (proven ? recent < 128 : (run != 0 && run < 128)) break;
         if (n >= cap || pos + 512 >= limit) break;
         // ---- the point that ended the run, by the serial decoder
         if (tid == 0) {
