@@ -232,7 +232,9 @@ struct Walk {
     uint32_t backoff;        // rows to the stride attempt after the next one that fails
     bool last_known;         // last_len / last_t1 say what the last point was
     bool want_tables;        // the last region was not one that strides carried
-    bool allow_pause, pause; // the walker may ask for / asks for the pipeline to stop here so that stride_phase() takes over
+    uint32_t pause_after;    // regions in a row that strides must carry before the walker asks for a pause (0: never)
+    uint32_t carried;        // regions in a row that strides have carried
+    bool pause;              // the walker asks for the pipeline to stop here so that stride_phase() takes over
     GTSC_WG_WALK_DECL
 };
 
@@ -663,7 +665,8 @@ __device__ __forceinline__ uint32_t walk_region_fast(Walk& w, WgLds& L, uint32_t
     const uint32_t found = read_lane(incl, 63);
     w.found_total += found;
     w.want_tables = 4 * stride_points < 3 * found || found == 0;
-    w.pause = w.allow_pause && !handover && found >= 64 && !w.want_tables;
+    w.carried = (!handover && found >= 32 && !w.want_tables) ? w.carried + 1 : 0u;
+    w.pause = w.pause_after != 0 && w.carried >= w.pause_after;
 
     GTSC_WG_WALK_TICK(w, tw_queue)
     return found;
@@ -905,11 +908,12 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
 
     // The block goes through two kinds of phases in turn: runs of plain points of equal length as far as they go
     // (stride_phase()), then the pipeline -- until the stream ends, or the walker sees it go by strides again and pauses.
-    bool allow_pause = true, proven = false;
+    uint32_t pause_after = 1;   // doubles with every pause that bought little
+    bool proven = false;
     for (;;) {
     if (!finished && !serial) {
         const uint32_t by_runs = stride_phase<FMT, NW>(a, image, nw, p0, cap, limit, L, tid, pos, n, stored_delta, stored_ts, val, win, serial, proven);
-        if (proven && by_runs < 512) allow_pause = false;   // (a pause that bought this little is not worth another)
+        if (proven) pause_after = by_runs >= 512 ? 1u : pause_after < 64 ? pause_after * 2 : 0u;
     }
     bool paused = false;
 
@@ -944,7 +948,7 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
         if (tid == 0) { L.landwnb[k0 & 1u] = win & 127u; L.landwnb[(k0 & 1u) ^ 1u] = 0xFFFFFFFFu; L.curwnb = win & 127u; L.want_tables = 1; }
         wg_barrier();
 
-        Walk wk{pos, win & 127u, win >> 7, 0u, false, 0u, n, false, false, 8u, true, true, allow_pause, false};
+        Walk wk{pos, win & 127u, win >> 7, 0u, false, 0u, n, false, false, 8u, true, true, pause_after, 0u, false};
         GTSC_WG_STAMP_DECL
         bool stop_prev = false;       // the walker stopped in the tick before: this one only emits
         uint32_t qprev = 0;           // points the walker queued in the tick before
