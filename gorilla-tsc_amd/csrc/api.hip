@@ -82,11 +82,12 @@ constexpr size_t FLAG_BLOCK_BYTES = 64;
 // gauges at 5 bits lose 8 %, drifting gauges at 47 bits gain 3 %, random walks and random doubles 10 %).
 constexpr uint64_t DENSE_BITS_PER_POINT = 40;
 
-// The host pipeline has three streams -- all copy-ins, all kernels, all copy-outs, each back to back -- and
-// NSTAGE sets of device buffers that chunks take in turn, tied together by events.  With the context's own
-// stream that makes four streams: the HIP runtime maps streams onto four hardware queues by default
-// (GPU_MAX_HW_QUEUES), and streams that share a queue run in order (a copy-in behind another chunk's kernels).
-constexpr int NSTAGE = 3;
+// The host pipeline has four streams -- all copy-ins, all kernels but one, the workgroup-per-block decompressor
+// beside them, all copy-outs, each back to back -- and NSTAGE sets of device buffers that chunks take in turn, tied
+// together by events.  The HIP runtime maps the streams of one priority onto four hardware queues by default
+// (GPU_MAX_HW_QUEUES), and streams that share a queue run in order (a copy-out behind another chunk's kernels): see
+// ensure_stage_streams() for how the copy streams are kept apart from the others.
+constexpr int NSTAGE = 4;
 
 struct gtsc_ctx {
     int device = 0;
@@ -112,10 +113,11 @@ struct gtsc_ctx {
     uint32_t dfcm_mask = 0;
     DeviceBuf dfcm_tables[1 + NSTAGE];  // device entry points, then one per stage of the host pipeline
     // staging for the host entry points
-    hipStream_t copy_in = nullptr, work = nullptr, copy_out = nullptr;
+    hipStream_t copy_in = nullptr, work = nullptr, copy_out = nullptr, work2 = nullptr;
+    hipEvent_t dev_planned = nullptr, dev_joined = nullptr;   // the device entry point's fork onto work2 (see DecodeFork)
     struct Stage {
         // the chunk's input has arrived / its kernels are done / its results have left the stage's buffers
-        hipEvent_t copied_in = nullptr, coded = nullptr, drained = nullptr;
+        hipEvent_t copied_in = nullptr, coded = nullptr, drained = nullptr, planned = nullptr, joined = nullptr;
         HostBuf h_off_a, h_off_b;   // this chunk's offset arrays, rebased to the chunk
         DeviceBuf block_ts, ts, val, pt_off, slots, slot_off, nwords, nbits, coff, compact, status, npoints;
     } stage[NSTAGE];
@@ -264,10 +266,11 @@ int gtsc_destroy(gtsc_ctx* c)
     if (!c) return GTSC_OK;
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (hipStream_t q : {c->copy_in, c->work, c->copy_out})
+    for (hipStream_t q : {c->copy_in, c->work, c->copy_out, c->work2})
         if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (hipEvent_t e : {c->dev_planned, c->dev_joined}) if (e) (void)hipEventDestroy(e);
     for (auto& s : c->stage) {
-        for (hipEvent_t e : {s.copied_in, s.coded, s.drained}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {s.copied_in, s.coded, s.drained, s.planned, s.joined}) if (e) (void)hipEventDestroy(e);
         s.h_off_a.release(); s.h_off_b.release();
         for (DeviceBuf* b : {&s.block_ts, &s.ts, &s.val, &s.pt_off, &s.slots, &s.slot_off, &s.nwords, &s.nbits, &s.coff,
                              &s.compact, &s.status, &s.npoints})
@@ -446,7 +449,15 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     c->last_dispatch = 0;
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
                  out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, ~0ull, nullptr, c->d_plans, 0u, 0u, c->tun, &c->last_dispatch};
-    HIP_TRY(launch_decode(a, format, c->stream));
+    // a ragged batch may have blocks for all three decompressors: the workgroup one runs beside the other two
+    DecodeFork fork{};
+    if (pt_off) {
+        if (!c->work2) HIP_TRY(hipStreamCreateWithFlags(&c->work2, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&c->dev_planned, &c->dev_joined})
+            if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        fork = DecodeFork{c->work2, c->dev_planned, c->dev_joined};
+    }
+    HIP_TRY(launch_decode(a, format, c->stream, pt_off ? &fork : nullptr));
     return GTSC_OK;
 }
 
@@ -494,7 +505,7 @@ int gtsc_host_pipeline_idle(gtsc_ctx* c)
 {
     if (int rc = check_ctx(c)) return rc;
     DeviceGuard g(c->device);
-    for (hipStream_t q : {c->copy_in, c->work, c->copy_out}) {
+    for (hipStream_t q : {c->copy_in, c->work, c->copy_out, c->work2}) {
         if (!q) continue;
         const hipError_t e = hipStreamQuery(q);
         if (e == hipErrorNotReady) return 0;
@@ -522,31 +533,32 @@ void gtsc_host_free(void* p)
 
 namespace {
 
-// Points per chunk of the host pipeline.  Decompression of a block is a chain (where a point starts is only
-// known from the points before it), so a chunk takes at least as long as its longest block: large chunks, so
-// that the long blocks of a batch run side by side.  Compression has no such chain (a long block is spread
-// over the lanes of a wave), and smaller chunks let the copy of one chunk hide the work on the previous one.
-constexpr uint64_t CHUNK_POINTS = 64ull << 20;         // 1 GiB of raw points
+// Points per chunk of the host pipeline.  Compression has no chain along a block (a long block is spread over the
+// lanes of a wave), and chunks of 256 MiB let the copy of one hide the work on the one before.  Decompression of a
+// block is a chain (where a point starts is only known from the points before it), so a chunk's kernels take as long
+// as its longest block whatever its size -- about 4 ms with 100,000-point blocks, the time it takes to copy out 14
+// million points: chunks of 16 Mi points keep the copies out back to back.  But the runtime's copies out slow down
+// once a call has made more than two dozen of them (every sixteenth, from about the twenty-eighth on, takes four and
+// a half times as long, whatever the chunk size: 268 million points in 16 Mi chunks decode at 33 GB/s, in 64 Mi
+// chunks at 54): a call is cut into six chunks or fewer where chunks of 64 Mi points allow that.
+constexpr uint64_t CHUNK_POINTS = 64ull << 20;         // 1 GiB of raw points: the largest chunk
 constexpr uint64_t ENCODE_CHUNK_POINTS = 16ull << 20;  // 256 MiB
+constexpr uint64_t DECODE_CHUNK_POINTS = 16ull << 20;  // the smallest chunk of a large batch
+constexpr uint64_t DECODE_CHUNKS = 6;
 constexpr uint64_t CHUNK_SERIES = 4ull << 20;
 
 // Chunk size in points; GTSC_CHUNK_POINTS overrides it (tests use it to get many chunks from a small batch).
-uint64_t chunk_points(bool encode)
+uint64_t chunk_points(bool encode, uint64_t total_points)
 {
-    if (encode) {
-        static const uint64_t v = [] {
-            const char* e = getenv("GTSC_CHUNK_POINTS");
-            const uint64_t n = e ? strtoull(e, nullptr, 10) : 0;
-            return n ? (n < CHUNK_POINTS ? n : CHUNK_POINTS) : ENCODE_CHUNK_POINTS;
-        }();
-        return v;
-    }
-    static const uint64_t v = [] {
+    static const uint64_t forced = [] {
         const char* e = getenv("GTSC_CHUNK_POINTS");
         const uint64_t n = e ? strtoull(e, nullptr, 10) : 0;
-        return n ? (n < CHUNK_POINTS ? n : CHUNK_POINTS) : CHUNK_POINTS;
+        return n < CHUNK_POINTS ? n : CHUNK_POINTS;
     }();
-    return v;
+    if (forced) return forced;
+    if (encode) return ENCODE_CHUNK_POINTS;
+    const uint64_t even = (total_points + DECODE_CHUNKS - 1) / DECODE_CHUNKS;
+    return even < DECODE_CHUNK_POINTS ? DECODE_CHUNK_POINTS : even > CHUNK_POINTS ? CHUNK_POINTS : even;
 }
 
 struct Chunk { uint64_t s0, s1; };
@@ -555,12 +567,13 @@ struct Chunk { uint64_t s0, s1; };
 std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t uniform, bool encode)
 {
     std::vector<Chunk> out;
+    const uint64_t most = chunk_points(encode, off ? off[nseries] - off[0] : nseries * uniform);
     uint64_t s = 0;
     while (s < nseries) {
         uint64_t e = s, pts = 0;
         while (e < nseries && e - s < CHUNK_SERIES) {
             const uint64_t n = off ? off[e + 1] - off[e] : uniform;
-            if (e > s && pts + n > chunk_points(encode)) break;
+            if (e > s && pts + n > most) break;
             pts += n;
             e++;
         }
@@ -572,10 +585,19 @@ std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t u
 
 int ensure_stage_streams(gtsc_ctx* c)
 {
-    for (hipStream_t* q : {&c->copy_in, &c->work, &c->copy_out})
+    // The runtime hands streams of one priority a small pool of hardware queues (four by default), and streams that
+    // share a queue run in order -- a copy-out behind the next chunk's kernels.  The two copy streams are made with
+    // the highest priority: that is a pool of their own, and what they move is what everything else waits for.
+    // (Two and no more: with a third stream of that priority in the process, calls of many chunks stalled for
+    // tens of seconds on the box this was measured on.)
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (hipStream_t* q : {&c->copy_in, &c->copy_out})
+        if (!*q) HIP_TRY(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
+    for (hipStream_t* q : {&c->work, &c->work2})
         if (!*q) HIP_TRY(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
     for (auto& st : c->stage)
-        for (hipEvent_t* e : {&st.copied_in, &st.coded, &st.drained})
+        for (hipEvent_t* e : {&st.copied_in, &st.coded, &st.drained, &st.planned, &st.joined})
             if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return GTSC_OK;
 }
@@ -588,7 +610,7 @@ struct PipelineDrain {
     gtsc_ctx* c;
     ~PipelineDrain()
     {
-        for (hipStream_t q : {c->copy_in, c->work, c->copy_out})
+        for (hipStream_t q : {c->copy_in, c->work, c->copy_out, c->work2})
             if (q) (void)hipStreamSynchronize(q);
     }
 };
@@ -786,16 +808,18 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         HIP_TRY(st.status.reserve(ns * 4));
         if (nw) HIP_TRY(hipMemcpyAsync(st.compact.p, words + w0, nw * 8, hipMemcpyHostToDevice, c->copy_in));
         HIP_TRY(hipEventRecord(st.copied_in, c->copy_in));
-        HIP_TRY(hipStreamWaitEvent(c->work, st.copied_in, 0));
+        const hipStream_t work = c->work;
+        HIP_TRY(hipStreamWaitEvent(work, st.copied_in, 0));
         DecodeArgs a{ns, st.compact.as<uint64_t>(), Layout{st.slot_off.as<uint64_t>(), 0}, nullptr, st.ts.as<int64_t>(),
                      st.val.as<uint64_t>(), Layout{d_pt_off, uniform_capacity}, st.npoints.as<uint64_t>(),
                      st.status.as<uint32_t>(), c->d_flags_host, nullptr, c->dfcm_mask, 0u, ~0ull, nullptr, c->d_plans + 1 + b, 0u, 0u,
                      c->tun, nullptr};
         // the host form knows the chunk's density: no need to let the device choose the ring
         if (a.tun.decode_ring == 0) a.tun.decode_ring = nw * 64 > np * DENSE_BITS_PER_POINT ? 16u : 8u;
-        HIP_TRY(dfcm_prepare(c, 1 + b, ns, c->work, &a.dfcm_tables));
-        HIP_TRY(launch_decode(a, format, c->work));
-        HIP_TRY(hipEventRecord(st.coded, c->work));
+        HIP_TRY(dfcm_prepare(c, 1 + b, ns, work, &a.dfcm_tables));
+        const DecodeFork fork{c->work2, st.planned, st.joined};
+        HIP_TRY(launch_decode(a, format, work, &fork));
+        HIP_TRY(hipEventRecord(st.coded, work));
         HIP_TRY(hipStreamWaitEvent(c->copy_out, st.coded, 0));
         if (np) {
             HIP_TRY(hipMemcpyAsync(ts + p0, st.ts.p, np * 8, hipMemcpyDeviceToHost, c->copy_out));
@@ -806,6 +830,7 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         HIP_TRY(hipEventRecord(st.drained, c->copy_out));
     }
     HIP_TRY(hipStreamSynchronize(c->work));
+    HIP_TRY(hipStreamSynchronize(c->work2));
     HIP_TRY(hipStreamSynchronize(c->copy_out));
     uint32_t flags = 0;
     if (int rc = read_flags(c, c->work, &flags)) return rc;

@@ -919,15 +919,15 @@ __global__ __launch_bounds__(256) void plan_decode_kernel(DecodeArgs a, DecodePl
 {
     // Every thread sums over its series, a workgroup adds its threads up through LDS, and one thread adds the six
     // sums to the plan: few atomics on the same six words however many series there are.
-    __shared__ unsigned long long part[4][8];
+    __shared__ unsigned long long part[4][8], part2[4];
     unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long longest = 0;
+    unsigned long long longest = 0, widest = 0;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.nseries; s += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t cap = a.pts.size(s);
         const bool is_long = cap >= a.tun.long_points, is_vlong = cap >= a.tun.vlong_points;
         const bool sampled = (s & 63u) == 0;
         const uint64_t nw = (is_long || sampled) ? (a.in_nwords ? a.in_nwords[s] : a.slots.size(s)) : 0;
-        if (is_long) { acc[0]++; acc[2] += nw; acc[3] += cap; }
+        if (is_long) { acc[0]++; acc[2] += nw; acc[3] += cap; widest = nw > widest ? nw : widest; }
         if (is_vlong) {
             acc[1]++;
             if (nw * 64 < cap * a.tun.wg_dense_bits) { acc[6] += cap; longest = cap > longest ? cap : longest; }
@@ -944,7 +944,12 @@ __global__ __launch_bounds__(256) void plan_decode_kernel(DecodeArgs a, DecodePl
                                      (uint32_t)__shfl_xor((int)(uint32_t)longest, d, 64);
         longest = o > longest ? o : longest;
     }
-    if (lane == 0) part[wave][7] = longest;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(widest >> 32), d, 64) << 32) |
+                                     (uint32_t)__shfl_xor((int)(uint32_t)widest, d, 64);
+        widest = o > widest ? o : widest;
+    }
+    if (lane == 0) { part[wave][7] = longest; part2[wave] = widest; }
     __syncthreads();
     if (threadIdx.x < 7) {
         const unsigned long long t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
@@ -953,6 +958,10 @@ __global__ __launch_bounds__(256) void plan_decode_kernel(DecodeArgs a, DecodePl
         unsigned long long t = part[0][7];
         for (int w = 1; w < 4; w++) t = part[w][7] > t ? part[w][7] : t;
         if (t) atomicMax(reinterpret_cast<unsigned long long*>(plan) + 7, t);
+    } else if (threadIdx.x == 8) {
+        unsigned long long t = part2[0];
+        for (int w = 1; w < 4; w++) t = part2[w] > t ? part2[w] : t;
+        if (t) atomicMax(reinterpret_cast<unsigned long long*>(plan) + 8, t);
     }
 }
 
@@ -987,7 +996,7 @@ namespace gtsc {
 
 hipError_t launch_decode_plan(const DecodeArgs& a, hipStream_t stream)
 {
-    if (hipError_t e = hipMemsetAsync(a.plan_buf, 0, sizeof(DecodePlan), stream)) return e;
+    if (hipError_t e = hipMemsetAsync(a.plan_buf, 0, DecodePlan::HEADER_BYTES, stream)) return e;
     if (a.nseries == 0) return hipSuccess;
     if (a.dispatch) *a.dispatch |= DISPATCH_PLAN;
     const uint64_t groups = (a.nseries + 255) / 256;

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "codec_device.hpp"
 #include "diag.hpp"   // measurement hooks: empty in the shipped library
@@ -111,7 +112,13 @@ struct WgLds {
     uint32_t curwnb;               // the walker's window size when it last reported
     uint32_t want_tables;          // ... and whether it has use for tables (not while strides carry it)
     uint32_t pad_[14];             // (a row's table is read one row ahead, past the last row too)
+#ifndef GTSC_WG_SHARE_UNIT
+    // More than half a compute unit's 160 KB, so that a workgroup has its unit to itself: two on one unit run at half
+    // speed each, and a block is a chain -- what a batch waits for is its slowest block, not the sum.
+    uint32_t alone_[1800];
+#endif
 };
+static_assert(sizeof(WgLds) <= 160 * 1024, "more LDS than a compute unit has");
 
 // Where the chain leaves a row, for each of the 64 places it may enter it -- worked out by the classifier waves for
 // the rows they classified, with one pointer-doubling pass per row: lane l starts with where position l lands and
@@ -709,7 +716,7 @@ __device__ __forceinline__ uint32_t stride_phase(const DecodeArgs& a, const uint
     const uint32_t lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     auto src = [&](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
-    uint32_t runs = 0, empty_runs = 0, accepted = 0, parity = 0;
+    uint32_t empty_runs = 0, accepted = 0, parity = 0;
     uint32_t recent = 1024;   // about eight times the length of the last few runs
     for (;;) {
         // ---- a run from `pos` on: unchanged points at a regular interval first ('00' each: as many as half the zero
@@ -812,13 +819,12 @@ __device__ __forceinline__ uint32_t stride_phase(const DecodeArgs& a, const uint
             }
             parity ^= 1u;
         }
-        runs++;
         accepted += run;
         empty_runs = run ? 0u : empty_runs + 1u;
         recent = recent - (recent >> 3) + (run < 1024 ? run : 1024u);
-        // most blocks are not of this kind: three points in a row that start no run, a short run (at a block's start:
+        // most blocks are not of this kind: three points in a row that start no run (eight, later on), a short run (at a block's start:
         // one look is all such a block should pay for) or runs that have become short (later on)
-        if (empty_runs >= 3) break;
+        if (empty_runs >= (proven ? 8u : 3u)) break;
         if (proven ? recent < 128 : (run != 0 && run < 128)) break;
         if (n >= cap || pos + 512 >= limit) break;
         // ---- the point that ended the run, by the serial decoder
@@ -914,6 +920,7 @@ __device__ __forceinline__ void decode_block_wg(const DecodeArgs& a, uint64_t s,
     if (!finished && !serial) {
         const uint32_t by_runs = stride_phase<FMT, NW>(a, image, nw, p0, cap, limit, L, tid, pos, n, stored_delta, stored_ts, val, win, serial, proven);
         if (proven) pause_after = by_runs >= 512 ? 1u : pause_after < 64 ? pause_after * 2 : 0u;
+        GTSC_WG_RUN_PHASE_PRINT(by_runs, n, pos, win, serial)
     }
     bool paused = false;
 
@@ -1199,17 +1206,102 @@ __global__ __launch_bounds__(64 * NW) void decode_block_wg_kernel(DecodeArgs a, 
     }
 }
 
+// The blocks of the workgroup-per-block decompressor, listed by size class (DecodePlan::queue_*): class 0 holds the
+// largest long image of the batch, class c those of at least (15 - c) fifteenths of its words.  (The order inside
+// a class is whatever the atomics make it.)
+template <int FMT>
+__global__ __launch_bounds__(256) void wg_queue_kernel(DecodeArgs a, DecodePlan* plan)
+{
+    const uint64_t widest = plan->words_longest;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.nseries; s += (uint64_t)gridDim.x * blockDim.x) {
+        if (block_owner<FMT>(a, s) != OWNER_WG) continue;
+        uint64_t nw = a.in_nwords ? a.in_nwords[s] : a.slots.size(s);
+        nw = nw < widest ? nw : widest;
+        const uint32_t cls = DecodePlan::QUEUE_CLASSES - 1 - (uint32_t)(nw * (DecodePlan::QUEUE_CLASSES - 1) / (widest ? widest : 1));
+        const uint32_t at = atomicAdd(&plan->queue_count[cls], 1u);
+        if (at < DecodePlan::QUEUE_CAP) plan->queue_list[cls][at] = (uint32_t)s;
+        else atomicOr(&plan->queue_overflow, 1u);
+    }
+}
+
+// As many workgroups as the device has compute units, each drawing its next block from the plan's lists, largest
+// images first.  Where a list overflowed the workgroups go through the series by number instead.
+template <int FMT, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void decode_block_wg_queue_kernel(DecodeArgs a, DecodePlan* plan)
+{
+    __shared__ WgLds L;
+    __shared__ uint32_t drawn;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (plan->queue_overflow) {
+        for (uint64_t base = (uint64_t)blockIdx.x * 64; base < a.nseries; base += (uint64_t)gridDim.x * 64) {
+            const uint64_t cand = base + lane;
+            const bool mine = cand < a.nseries && block_owner<FMT>(a, cand) == OWNER_WG;
+            uint64_t todo = lanes(mine);   // (the same in every wave)
+            while (todo) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                decode_block_wg<FMT, NW>(a, base + j, L, tid);
+                __syncthreads();   // the next block starts over in LDS
+            }
+        }
+        return;
+    }
+    // lane c: the tickets of the classes before class c
+    const uint32_t mine = lane < DecodePlan::QUEUE_CLASSES ? plan->queue_count[lane] : 0u;
+    const uint32_t upto = wave_inclusive_sum(mine);
+    const uint32_t total = read_lane(upto, 63);
+    for (;;) {
+        if (tid == 0) drawn = atomicAdd(&plan->queue_ticket, 1u);
+        __syncthreads();
+        const uint32_t t = drawn;
+        __syncthreads();
+        if (t >= total) break;
+        const uint32_t cls = (uint32_t)__builtin_popcountll(lanes(lane < DecodePlan::QUEUE_CLASSES && upto <= t));
+        const uint32_t first = cls ? read_lane(upto, cls - 1) : 0u;
+        decode_block_wg<FMT, NW>(a, plan->queue_list[cls][t - first], L, tid);
+        __syncthreads();
+    }
+}
+
+// compute units of the current device (remembered per device)
+uint32_t compute_units()
+{
+    static std::atomic<uint32_t> known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    uint32_t n = known[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        int v = 0;
+        n = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? (uint32_t)v : 256u;
+        known[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 }  // namespace
 
 hipError_t launch_decode_blocks_wg(const DecodeArgs& a, int format, hipStream_t stream)
 {
     if (a.nseries == 0) return hipSuccess;
     if (a.dispatch) *a.dispatch |= DISPATCH_WG;
-    uint64_t per_group = a.nseries / 16384;
-    per_group = per_group < 1 ? 1 : per_group > 64 ? 64 : per_group;
-    const uint32_t grid = (uint32_t)((a.nseries + per_group - 1) / per_group);
-    if (format == FMT_V2) hipLaunchKernelGGL((decode_block_wg_kernel<FMT_V2, 16>), dim3(grid), dim3(64 * 16), 0, stream, a, (uint32_t)per_group);
-    else                  hipLaunchKernelGGL((decode_block_wg_kernel<FMT_V1, 16>), dim3(grid), dim3(64 * 16), 0, stream, a, (uint32_t)per_group);
+    const uint32_t units = compute_units();
+    if (a.nseries <= units || a.nseries > 0xFFFFFFFFull) {
+        // a workgroup per series (they all start at once), or sixty-four series each where there are billions
+        const uint64_t per_group = a.nseries <= units ? 1 : 64;
+        const uint32_t grid = (uint32_t)((a.nseries + per_group - 1) / per_group);
+        if (format == FMT_V2) hipLaunchKernelGGL((decode_block_wg_kernel<FMT_V2, 16>), dim3(grid), dim3(64 * 16), 0, stream, a, (uint32_t)per_group);
+        else                  hipLaunchKernelGGL((decode_block_wg_kernel<FMT_V1, 16>), dim3(grid), dim3(64 * 16), 0, stream, a, (uint32_t)per_group);
+        return hipGetLastError();
+    }
+    const uint64_t groups = (a.nseries + 255) / 256;
+    const uint32_t lgrid = (uint32_t)(groups < 1024 ? groups : 1024);
+    if (format == FMT_V2) {
+        hipLaunchKernelGGL(wg_queue_kernel<FMT_V2>, dim3(lgrid), dim3(256), 0, stream, a, a.plan_buf);
+        hipLaunchKernelGGL((decode_block_wg_queue_kernel<FMT_V2, 16>), dim3(units), dim3(64 * 16), 0, stream, a, a.plan_buf);
+    } else {
+        hipLaunchKernelGGL(wg_queue_kernel<FMT_V1>, dim3(lgrid), dim3(256), 0, stream, a, a.plan_buf);
+        hipLaunchKernelGGL((decode_block_wg_queue_kernel<FMT_V1, 16>), dim3(units), dim3(64 * 16), 0, stream, a, a.plan_buf);
+    }
     return hipGetLastError();
 }
 

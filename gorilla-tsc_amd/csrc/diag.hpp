@@ -124,6 +124,7 @@ constexpr bool DIAG_STAMPED = false;
 #define GTSC_WG_WALK_TICK(W_, acc_) { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); (W_).acc_ += now_ - (W_).tw_prev; (W_).tw_prev = now_; __builtin_amdgcn_sched_barrier(0); }
 #define GTSC_WG_WALK_COUNT(W_, cnt_) (W_).cnt_++;
 #define GTSC_WG_WALK_PRINT(W_) if (lane == 0 && wave == 0) printf("walker: chase %llu enum %llu rows %llu (%u calls) strides %llu (%u) queue %llu careful %llu (%u handovers)\n", (unsigned long long)(W_).tw_chase, (unsigned long long)(W_).tw_enum, (unsigned long long)(W_).tw_rows, (W_).tw_calls, (unsigned long long)(W_).tw_stride, (W_).tw_strides, (unsigned long long)(W_).tw_queue, (unsigned long long)(W_).tw_careful, (W_).tw_handover);
+#define GTSC_WG_RUN_PHASE_PRINT(by_runs_, n_, pos_, win_, serial_) if (tid == 0) printf("run phase: %u points by runs, now at point %u, bit %llu, window %u, serial %d\n", (by_runs_), (n_), (unsigned long long)(pos_), (win_) & 127u, (int)(serial_));
 #define GTSC_WG_STAMP_PRINT if (lane == 0 && wave < 2) printf("wave %u: x1 %llu x2 %llu b1 %llu y %llu b2 %llu z %llu other %llu\n", wave, (unsigned long long)tk_x1, (unsigned long long)tk_x2, (unsigned long long)tk_b1, (unsigned long long)tk_y, (unsigned long long)tk_b2, (unsigned long long)tk_z, (unsigned long long)tk_other);
 #else
 #define GTSC_WG_STAMP_DECL
@@ -133,5 +134,6 @@ constexpr bool DIAG_STAMPED = false;
 #define GTSC_WG_WALK_TICK(W_, acc_)
 #define GTSC_WG_WALK_COUNT(W_, cnt_)
 #define GTSC_WG_WALK_PRINT(W_)
+#define GTSC_WG_RUN_PHASE_PRINT(by_runs_, n_, pos_, win_, serial_)
 #define GTSC_WG_STAMP_PRINT
 #endif

@@ -1503,9 +1503,12 @@ static bool deep_ring_pays(uint32_t waves)
 // Which kernels decode a batch follows from the batch alone.  Series with a capacity of at least long_points points
 // ("long" blocks) may get a wave or a workgroup each instead of a lane: plan_decode_kernel counts them and measures
 // their density on the device, and every kernel launched here asks block_owner() about each series -- the three
-// kernels run over the batch one after the other, and each takes its own blocks.  A uniform batch of short series (the
+// kernels run over the batch and each takes its own blocks (the workgroup-per-block one on a stream of its own where
+// the caller has one to give: see DecodeFork).  A uniform batch of short series (the
 // headline workload) launches the lane-per-series kernel alone.
-hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
+static hipError_t launch_decode_lanes(const DecodeArgs& a, int format, hipStream_t stream, bool ring_auto, uint32_t& did);
+
+hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream, const DecodeFork* fork)
 {
     if (a0.nseries == 0) return hipSuccess;
     DecodeArgs a = a0;
@@ -1526,11 +1529,34 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream)
         const bool wg_possible = a.pts.off || nlong <= a.tun.wg_decode_max || (a.pts.uniform >= a.tun.vlong_points && nlong <= a.tun.wg_decode_vlong_max);
         const uint64_t wave_most = a.tun.wave_decode_max > a.tun.wave_decode_max_dense ? a.tun.wave_decode_max : a.tun.wave_decode_max_dense;
         const bool wave_possible = a.pts.off || nlong <= wave_most;
-        if (wg_possible) if (hipError_t e = launch_decode_blocks_wg(a, format, stream)) return e;
+        bool joined = true;
+        if (wg_possible) {
+            if (fork && a.pts.off) {   // (a uniform batch of long blocks goes to one kernel as a whole: nothing to run beside it)
+                if (hipError_t e = hipEventRecord(fork->planned, stream)) return e;
+                if (hipError_t e = hipStreamWaitEvent(fork->side, fork->planned, 0)) return e;
+                if (hipError_t e = launch_decode_blocks_wg(a, format, fork->side)) return e;
+                if (hipError_t e = hipEventRecord(fork->joined, fork->side)) return e;
+                joined = false;
+            } else if (hipError_t e = launch_decode_blocks_wg(a, format, stream)) return e;
+        }
         if (wave_possible) if (hipError_t e = launch_decode_blocks(a, format, stream)) return e;
-        if (!a.pts.off && a.tun.long_points == 0 && a.tun.wave_decode_max >= a.nseries && a.tun.wave_decode_max_dense >= a.nseries)
-            return hipGetLastError();  // every block is "long" and a wave or workgroup takes it whatever the plan says: nothing is left for the lanes
+        if (!a.pts.off && a.tun.long_points == 0 && a.tun.wave_decode_max >= a.nseries && a.tun.wave_decode_max_dense >= a.nseries) {
+            // every block is "long" and a wave or workgroup takes it whatever the plan says: nothing is left for the lanes
+            if (!joined) if (hipError_t e = hipStreamWaitEvent(stream, fork->joined, 0)) return e;
+            return hipGetLastError();
+        }
+        if (!joined) {
+            const hipError_t e = launch_decode_lanes(a, format, stream, ring_auto, did);
+            if (hipError_t w = hipStreamWaitEvent(stream, fork->joined, 0)) return w;
+            return e;
+        }
     }
+    return launch_decode_lanes(a, format, stream, ring_auto, did);
+}
+
+// the lane-per-series kernels of a batch (they leave alone what block_owner() gives to the other two)
+static hipError_t launch_decode_lanes(const DecodeArgs& a, int format, hipStream_t stream, bool ring_auto, uint32_t& did)
+{
     if (a.dfcm_tables) {
         if (format != FMT_V2) return hipErrorInvalidValue;
         const uint32_t blocks = (uint32_t)((a.nseries + 255) / 256);

@@ -59,6 +59,18 @@ struct DecodePlan {
     uint64_t words_all, cap_all;     // the same over every 64th series of the batch
     uint64_t cap_vlong_sparse;       // capacities of the very long series with sparse images, summed ...
     uint64_t cap_vlong_longest;      // ... and the largest of them
+    uint64_t words_longest;          // the largest image among the long ones
+    // The workgroup-per-block decompressor's blocks, largest images first (wg_queue_kernel fills it in where a batch
+    // has more series than the device has compute units): sixteen classes by image size relative to the largest,
+    // each a list of series numbers, and the ticket the workgroups draw their next block with.  A block takes as
+    // long as its chain of points, whatever else runs: the long ones must start first, or the last of them to be
+    // drawn is what the whole batch waits for.
+    static constexpr uint32_t QUEUE_CLASSES = 16, QUEUE_CAP = 2048;
+    uint32_t queue_count[QUEUE_CLASSES];
+    uint32_t queue_ticket;
+    uint32_t queue_overflow;         // a class had more blocks than its list holds: the workgroups go by series number instead
+    uint32_t queue_list[QUEUE_CLASSES][QUEUE_CAP];
+    static constexpr size_t HEADER_BYTES = 9 * 8 + (QUEUE_CLASSES + 2) * 4;   // what a new plan zeroes
 };
 
 struct DecodeArgs {
@@ -138,7 +150,11 @@ __device__ __forceinline__ int block_owner(const DecodeArgs& a, uint64_t s)
 hipError_t launch_encode(const EncodeArgs& a, int format, hipStream_t stream);
 // wave-per-block compressor over the series of `a` with at least a.long_threshold points (block_codec.hip)
 hipError_t launch_encode_blocks(const EncodeArgs& a, int format, hipStream_t stream);
-hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream);
+// A second stream for launch_decode: the workgroup-per-block decompressor goes there, beside the other kernels of
+// the batch instead of before them (each of the three is as slow as its longest block and leaves most of the
+// device idle towards its end).  `planned` and `joined` are events of the caller's, used for nothing else.
+struct DecodeFork { hipStream_t side; hipEvent_t planned, joined; };
+hipError_t launch_decode(const DecodeArgs& a, int format, hipStream_t stream, const DecodeFork* fork = nullptr);
 // wave-per-block decompressor (block_codec.hip) and workgroup-per-block decompressor (block_decode_wg.hip): each
 // takes the series of `a` that block_owner() gives it
 hipError_t launch_decode_blocks(const DecodeArgs& a, int format, hipStream_t stream);

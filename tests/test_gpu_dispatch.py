@@ -199,6 +199,33 @@ def test_long_blocks_whose_character_changes_along_the_block(kernel):
         ctx.close()
 
 
+def test_workgroup_per_block_decoder_draws_its_blocks_largest_first():
+    """Batches of more series than the device has compute units: the workgroup-per-block decompressor lists its blocks
+    by size class on the device and its workgroups draw them largest first -- here with every block sent to it.  Skewed
+    lengths (about 700 series, every class of the list in use), and 2,400 series of one size (more than a class holds:
+    the workgroups fall back to going through the series by number).  Good and damaged images against the oracle."""
+    ctx = G.Context(0)
+    try:
+        for k, v in {G.TUNE_LONG_POINTS: 0, G.TUNE_WG_DECODE_MAX: HUGE, G.TUNE_WG_DENSE_BITS: 1 << 30,
+                     G.TUNE_WAVE_DECODE_MAX: HUGE, G.TUNE_WAVE_DECODE_MAX_DENSE: HUGE}.items():
+            ctx.set_tunable(k, v)
+        rng = np.random.default_rng(21)
+        skewed = synth.skewed(total_points=1500000, seed=31, pmin=10, pmax=20000)
+        same = synth.random_walk(S=2400, P=300, seed=32)
+        assert skewed.nseries > 400
+        for b, fmts in ((skewed, FMTS), (same, FMTS[:1])):
+            for gfmt, ofmt in fmts:
+                out, off, nw, _, _ = check_encode_against_oracle(ctx, b, gfmt, ofmt)
+                check_decode_against_oracle(ctx, out, off, nw, b.pt_off, gfmt, ofmt)
+                assert ctx.last_dispatch() & G.DISPATCH_WG
+                cut, zeroed, flipped = damage(out, off, nw, rng)
+                check_decode_against_oracle(ctx, out, off, cut, b.pt_off, gfmt, ofmt)
+                check_decode_against_oracle(ctx, zeroed, off, nw, b.pt_off, gfmt, ofmt)
+                check_decode_against_oracle(ctx, flipped, off, nw, b.pt_off, gfmt, ofmt)
+    finally:
+        ctx.close()
+
+
 def test_sparse_hint_sends_many_long_blocks_to_the_lane_per_series_compressor():
     """GTSC_TUNE_SPARSE_HINT (with the block count from which it applies set to zero): the same batch compressed a
     wavefront per block and a lane per block gives the oracle's words both ways, in both formats."""
