@@ -74,6 +74,10 @@ def make_workload(name, S, P, device, seed):
     elif name == "random_walk":
         cadence = 1000
         v = 100.0 + torch.cumsum(torch.randn((S, P), device=device, generator=g, dtype=torch.float64), dim=1)
+    elif name == "readme":
+        # the reference benchmark's own data: value = (double) i (G/benchmark/EncodingBenchmark.java:60-69)
+        cadence = 60
+        v = torch.arange(P, device=device, dtype=torch.float64).repeat(S, 1)
     elif name == "adversarial":
         cadence = 1000
         v = torch.randint(-2 ** 63, 2 ** 63 - 1, (S, P), device=device, generator=g, dtype=torch.int64).view(torch.float64)

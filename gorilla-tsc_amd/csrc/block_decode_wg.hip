@@ -1233,14 +1233,16 @@ __global__ __launch_bounds__(64 * NW) void decode_block_wg_queue_kernel(DecodeAr
     __shared__ uint32_t drawn;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (plan->queue_overflow) {
-        for (uint64_t base = (uint64_t)blockIdx.x * 64; base < a.nseries; base += (uint64_t)gridDim.x * 64) {
-            const uint64_t cand = base + lane;
+        // (workgroup g: series g, g + G, g + 2 G, ... -- neighbours in a batch tend to be alike, and this way they go
+        // to different workgroups)
+        for (uint64_t base = blockIdx.x; base < a.nseries; base += (uint64_t)gridDim.x * 64) {
+            const uint64_t cand = base + (uint64_t)lane * gridDim.x;
             const bool mine = cand < a.nseries && block_owner<FMT>(a, cand) == OWNER_WG;
             uint64_t todo = lanes(mine);   // (the same in every wave)
             while (todo) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
-                decode_block_wg<FMT, NW>(a, base + j, L, tid);
+                decode_block_wg<FMT, NW>(a, base + (uint64_t)j * gridDim.x, L, tid);
                 __syncthreads();   // the next block starts over in LDS
             }
         }

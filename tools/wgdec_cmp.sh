@@ -1,10 +1,10 @@
 # decode ms of S x P batches of long blocks through the three decompressors: lane-per-series ("tiled"), wave-per-block
-# ("wave"), workgroup-per-block ("wg"): bash tools/wgdec_cmp.sh [P] [S...]
+# ("wave"), workgroup-per-block ("wg"): [WL="workloads"] bash tools/wgdec_cmp.sh [P] [S...]
 P=${1:-7200}; shift
 SS=${*:-16 128 512 2048 8192}
 fmt='import json,sys; r=json.loads(sys.stdin.readline()); print("%8.3f ms" % r["roofline"]["decode_ms"])'
 for S in $SS; do
-for wl in gauge counter random_walk gauge_drift adversarial; do
+for wl in ${WL:-gauge counter random_walk gauge_drift adversarial}; do
   line="$wl ${S}x$P:"
   for k in tiled wave wg; do
     case $k in
