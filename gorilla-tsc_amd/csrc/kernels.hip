@@ -1531,7 +1531,9 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream, c
         const bool wave_possible = a.pts.off || nlong <= wave_most;
         bool joined = true;
         if (wg_possible) {
-            if (fork && a.pts.off) {   // (a uniform batch of long blocks goes to one kernel as a whole: nothing to run beside it)
+            // (a uniform batch of long blocks goes to one kernel as a whole: nothing to run beside it; and the hand-over
+            // between the streams costs a call of few blocks 30 us and buys it nothing)
+            if (fork && a.pts.off && a.nseries >= 256) {
                 if (hipError_t e = hipEventRecord(fork->planned, stream)) return e;
                 if (hipError_t e = hipStreamWaitEvent(fork->side, fork->planned, 0)) return e;
                 if (hipError_t e = launch_decode_blocks_wg(a, format, fork->side)) return e;
