@@ -298,10 +298,12 @@ int gtsc_compact_device_noalloc(gtsc_ctx *ctx, uint64_t nseries,
 /*
  * Host-memory forms: every pointer is host memory and the call returns when
  * the results are in the caller's arrays.  The batch is cut into chunks of
- * whole series that pass through three streams -- one for all copies in (two chunks ahead of the kernels), one for
+ * whole series that pass through four streams -- one for all copies in (two chunks ahead of the kernels), one for
  * the kernels (and the compressor's copy out, which the host can only enqueue once it knows the chunk's size), one
- * for the decompressor's copies out -- and three sets of device buffers that the chunks take in turn, tied together
- * by events, so that copies overlap kernels and each other.  Whatever the return code, nothing of the call is in
+ * beside it for the workgroup-per-block decompressor of a ragged chunk, one for the decompressor's copies out (the
+ * two copy streams are created with the highest stream priority, which gives them hardware queues of their own) --
+ * and four sets of device buffers that the chunks take in turn, tied together by events, so that copies overlap
+ * kernels and each other.  Whatever the return code, nothing of the call is in
  * flight any more when it returns: the caller may free or reuse its arrays.  Host arrays obtained
  * from gtsc_host_alloc() are page-locked and move by DMA at PCIe rate; other
  * memory works but is staged by the HIP runtime.
