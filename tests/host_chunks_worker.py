@@ -38,9 +38,15 @@ if mode == "fail":
     print("failure ok")
     raise SystemExit(0)
 
-if mode == "skewed":
-    # the skewed-length configuration: 10 to 100,000 points per series, constant / counter / random-walk series
-    b = synth.skewed(total_points=1 << 21, seed=0x5EED0005, pmin=10, pmax=100000)
+if mode in ("skewed", "skewed_many"):
+    # the skewed-length configuration: 10 to 100,000 points per series, constant / counter / random-walk series --
+    # or ("skewed_many") 10 to 20,000 points, so that a chunk holds several hundred series: more than the device has
+    # compute units, which is where the workgroup-per-block decompressor lists its blocks by size and runs on a
+    # stream of its own beside the other two
+    if mode == "skewed":
+        b = synth.skewed(total_points=1 << 21, seed=0x5EED0005, pmin=10, pmax=100000)
+    else:
+        b = synth.skewed(total_points=3 << 20, seed=0x5EED0006, pmin=10, pmax=20000)
     ctx = G.Context(0)
     for gfmt, ofmt in ((G.FMT_V2, O.V2), (G.FMT_V1, O.V1)):
         words, off, nbits = ctx.encode_host(b.block_ts, b.ts, b.val, pt_off=b.pt_off, fmt=gfmt, want_nbits=True)

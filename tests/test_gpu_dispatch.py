@@ -272,6 +272,16 @@ def test_skewed_lengths_through_the_host_entry_points():
     assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+def test_host_decode_with_the_workgroup_kernel_on_a_stream_of_its_own():
+    """Chunks of several hundred series of 10 to 20,000 points through the host entry points, against the oracle, both
+    formats: every chunk has more series than the device has compute units and blocks for all three decompressors, so
+    the workgroup-per-block one draws its blocks from the device-built list and runs beside the other two."""
+    env = dict(os.environ, GTSC_CHUNK_POINTS="1000000")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_chunks_worker.py"), "skewed_many"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_host_entry_points_leave_nothing_in_flight_after_an_error():
     """A failure half way through the chunked pipeline (injected where the third chunk is staged): the call returns the
     error and none of its copies is still under way, so the caller may free its arrays."""
