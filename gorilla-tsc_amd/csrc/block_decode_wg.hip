@@ -374,7 +374,8 @@ __device__ __forceinline__ uint32_t walk_region_careful(Walk& w, WgLds& L, uint3
 // The chain of hops through the rows of a region that lies well inside the image (no field of a point that starts
 // in it can run off the image; the capacity is the caller's to check afterwards), as one piece of assembly: the compiler's own
 // code for such a loop costs ten taken branches a row, and a lone wave pays a refill of its instruction buffer for
-// each.  Here a plain hop is a lane read, a bit set and a compare, and every second hop a taken branch.
+// each.  Here a plain hop is a lane read, a bit set and a compare, every second hop a taken branch, and a row's end
+// or a '11' code one more each.
 //
 // State: row r (< 64) and position q in it; `real`: the starts found in the row so far; lane l of `nxt` holds the
 // place in the row (64 and more: in the rows after it) where the chain lands from position l, or something above
@@ -403,7 +404,36 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t
         "ds_read_b32 %[hw], %[va]\n\t"
         "v_add_u32 %[va], 0x100, %[va]\n\t"
         "ds_read_b32 %[hwn], %[va]\n\t"
-        "s_waitcnt lgkmcnt(1)\n"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "s_branch 1f\n"
+        // (The blocks are laid out so that the common ways round -- a row done, a '11' code -- pay one taken branch
+        // each: a lone wave refills its instruction buffer for every one of them.)
+        "5:\n\t"   // the chain hopped over a whole row
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshl_add_u32 %[va], %[r], 8, %[base]\n\t"
+        "ds_read_b32 %[hw], %[va]\n\t"
+        "v_add_u32 %[va], 0x100, %[va]\n\t"
+        "ds_read_b32 %[hwn], %[va]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "s_branch 1f\n"
+        // ---- the row is done: the chain went from q to q2 >= 64
+        "30:\n\t"
+        "s_sub_u32 %[len], %[q2], %[q]\n\t"
+        "s_mov_b32 %[lastpos], %[q]\n\t"
+        "v_writelane_b32 %[blo], s96, m0\n\t"
+        "v_writelane_b32 %[bhi], s97, m0\n\t"
+        "s_mov_b64 s[96:97], 0\n\t"
+        "s_lshr_b32 %[t], %[q2], 6\n\t"
+        "s_add_u32 %[r], %[r], %[t]\n\t"
+        "s_and_b32 %[q], %[q2], 63\n\t"
+        "s_cmp_ge_u32 %[r], %[stoprow]\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "s_cmp_eq_u32 %[t], 1\n\t"
+        "s_cbranch_scc0 5b\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mov_b32 %[hw], %[hwn]\n\t"
+        "v_add_u32 %[va], 0x100, %[va]\n\t"
+        "ds_read_b32 %[hwn], %[va]\n"
         "1:\n\t"
         "s_mov_b32 m0, %[r]\n\t"
         "v_bfe_u32 %[vt], %[hw], 10, 1\n\t"
@@ -429,23 +459,11 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t
         "s_mov_b32 %[q2], %[t]\n"
         "20:\n\t"
         "s_cmp_lt_u32 %[q2], 512\n\t"
-        "s_cbranch_scc1 30f\n\t"
+        "s_cbranch_scc1 30b\n\t"
         // ---- position q is not a plain hop
         "v_readlane_b32 %[kk], %[hw], %[q]\n\t"
         "s_bitcmp1_b32 %[kk], 9\n\t"
-        "s_cbranch_scc0 22f\n\t"
-        "s_and_b32 %[q2], %[kk], 0x1ff\n\t"      // a run of '00' points: bits q, q + 2, ... up to where it lands
-        "s_sub_u32 %[t], %[q2], %[q]\n\t"
-        "s_sub_u32 %[t], 64, %[t]\n\t"
-        "s_lshr_b64 s[98:99], %[c5], %[t]\n\t"
-        "s_lshl_b64 s[98:99], s[98:99], %[q]\n\t"
-        "s_or_b64 s[96:97], s[96:97], s[98:99]\n\t"
-        "s_sub_u32 %[q], %[q2], 2\n\t"           // (the run's last point)
-        "s_cmp_lt_u32 %[q2], 64\n\t"
-        "s_cbranch_scc0 30f\n\t"
-        "s_mov_b32 %[q], %[q2]\n\t"
-        "s_branch 2b\n"
-        "22:\n\t"
+        "s_cbranch_scc1 23f\n\t"
         "s_and_b32 %[t], %[kk], 0x1400\n\t"      // an end marker, or a '10' code with no window to reuse: not this loop's
         "s_cbranch_scc1 29f\n\t"
         // a '11' code: the window it declares is in force from the next point on, and the positions of the row that
@@ -457,7 +475,19 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t
         "s_and_b32 %[q2], %[kk], 0x1ff\n\t"
         "v_mad_u32_u24 %[nxt], %[vt], %[wnbx], %[nxt]\n\t"
         "s_cmp_lt_u32 %[q2], 64\n\t"
-        "s_cbranch_scc0 30f\n\t"
+        "s_cbranch_scc0 30b\n\t"
+        "s_mov_b32 %[q], %[q2]\n\t"
+        "s_branch 2b\n"
+        "23:\n\t"
+        "s_and_b32 %[q2], %[kk], 0x1ff\n\t"      // a run of '00' points: bits q, q + 2, ... up to where it lands
+        "s_sub_u32 %[t], %[q2], %[q]\n\t"
+        "s_sub_u32 %[t], 64, %[t]\n\t"
+        "s_lshr_b64 s[98:99], %[c5], %[t]\n\t"
+        "s_lshl_b64 s[98:99], s[98:99], %[q]\n\t"
+        "s_or_b64 s[96:97], s[96:97], s[98:99]\n\t"
+        "s_sub_u32 %[q], %[q2], 2\n\t"           // (the run's last point)
+        "s_cmp_lt_u32 %[q2], 64\n\t"
+        "s_cbranch_scc0 30b\n\t"
         "s_mov_b32 %[q], %[q2]\n\t"
         "s_branch 2b\n"
         "29:\n\t"
@@ -465,33 +495,6 @@ __device__ __forceinline__ uint32_t walk_rows(uint32_t& r, uint32_t& q, uint64_t
         "s_mov_b32 %[kk], 2\n\t"
         "s_mov_b32 %[code], 2\n\t"
         "s_branch 10f\n"
-        // ---- the row is done: the chain went from q to q2 >= 64
-        "30:\n\t"
-        "s_sub_u32 %[len], %[q2], %[q]\n\t"
-        "s_mov_b32 %[lastpos], %[q]\n\t"
-        "v_writelane_b32 %[blo], s96, m0\n\t"
-        "v_writelane_b32 %[bhi], s97, m0\n\t"
-        "s_mov_b64 s[96:97], 0\n\t"
-        "s_lshr_b32 %[t], %[q2], 6\n\t"
-        "s_add_u32 %[r], %[r], %[t]\n\t"
-        "s_and_b32 %[q], %[q2], 63\n\t"
-        "s_cmp_ge_u32 %[r], %[stoprow]\n\t"
-        "s_cbranch_scc1 8f\n\t"
-        "s_cmp_eq_u32 %[t], 1\n\t"
-        "s_cbranch_scc0 5f\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mov_b32 %[hw], %[hwn]\n\t"
-        "v_add_u32 %[va], 0x100, %[va]\n\t"
-        "ds_read_b32 %[hwn], %[va]\n\t"
-        "s_branch 1b\n"
-        "5:\n\t"   // the chain hopped over a whole row
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshl_add_u32 %[va], %[r], 8, %[base]\n\t"
-        "ds_read_b32 %[hw], %[va]\n\t"
-        "v_add_u32 %[va], 0x100, %[va]\n\t"
-        "ds_read_b32 %[hwn], %[va]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "s_branch 1b\n"
         "8:\n\t"   // the last hop, for the caller: its length and whether it was a '10' code or part of a run
         "v_readlane_b32 %[t], %[hw], %[lastpos]\n\t"
         "s_and_b32 %[t], %[t], 0x600\n\t"

@@ -490,7 +490,7 @@ def test_host_entry_points_many_chunks():
 
 
 def test_full_size_1m_series_round_trip(ctx):
-    """BASELINE config: 1M series x 120 points.  Too big for a word-by-word oracle
+    """The headline configuration of the benchmark: 1M series x 120 points.  Too big for a word-by-word oracle
     comparison in test time, so: (a) decode(encode(x)) == x on the device for all
     120M points, (b) image lengths within the bound, (c) a strided sample of series
     checked against the oracle byte for byte."""
