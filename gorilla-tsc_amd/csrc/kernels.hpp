@@ -98,11 +98,13 @@ struct DecodeArgs {
     uint32_t* dispatch;       // as in EncodeArgs
 };
 
-// Whether the timestamps of an image stray from their cadence early on: what the delta-of-deltas of its points 3 to 6
-// say (two of the four not zero).  Dense streams with such timestamps have points of ever-changing length, which
-// is what the wave-per-block decompressor is slowest at.
+// What the first points of a dense image say about which decompressor suits it: true where its timestamps stray from
+// their cadence early on (two of the delta-of-deltas of points 3 to 6 not zero: such streams have points of
+// ever-changing length, which is what the wave-per-block decompressor is slowest at), and where points 7 to 10 are of
+// one length on a regular cadence (values that reuse one window, once the first few have settled it: the
+// workgroup-per-block decompressor takes such a stream 1,024 points a round).
 template <int FMT>
-__device__ inline bool strays_early(const uint64_t* image, uint64_t nw64)
+__device__ inline bool workgroup_suits_early(const uint64_t* image, uint64_t nw64)
 {
     const uint32_t nw = nw64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nw64;
     auto src = [image, nw](uint32_t i) -> uint64_t { return i < nw ? image[i] : 0ull; };
@@ -110,20 +112,25 @@ __device__ inline bool strays_early(const uint64_t* image, uint64_t nw64)
     d.begin(nw, src);
     int64_t t = 0, before = 0, delta = 0;
     uint64_t v;
-    uint32_t strays = 0;
-    for (int i = 0; i < 6; i++) {
+    uint32_t strays = 0, same_length = 0, length = 0;
+    for (int i = 0; i < 10; i++) {
+        const uint64_t at = (uint64_t)d.widx * 64 + d.off;
         if (!d.next(t, v, src)) return false;
+        const uint32_t bits = (uint32_t)((uint64_t)d.widx * 64 + d.off - at);
         if (i >= 2 && t - before != delta) strays++;
+        if (i == 5 && strays >= 2) return true;
+        if (i >= 6 && (i == 6 || bits == length)) same_length++;
+        length = bits;
         delta = t - before;
         before = t;
     }
-    return strays >= 2;
+    return strays == 0 && same_length == 4 && length > 3;
 }
 
 // Which decompressor takes series s: the lane-per-series kernel (a lane), the wave-per-block kernel or the
 // workgroup-per-block kernel.  Sparse streams of few or very long blocks get a workgroup each (it follows the chain
 // of point starts several times faster where points are short or irregular), and so do dense ones of few blocks
-// whose timestamps stray from their cadence; other long blocks get a wave each while the batch holds few enough of
+// whose timestamps stray from their cadence or whose points are of one length; other long blocks get a wave each while the batch holds few enough of
 // them to leave the lanes of the lane-per-series kernel mostly idle -- fewer when the images are dense, because
 // irregular long points are what the wave-per-block kernel is slowest at.
 constexpr int OWNER_LANE = 0, OWNER_WAVE = 1, OWNER_WG = 2;
@@ -141,7 +148,7 @@ __device__ __forceinline__ int block_owner(const DecodeArgs& a, uint64_t s)
                    (cap >= a.tun.vlong_points && pl.cap_vlong_sparse <= a.tun.wg_decode_vlong_max * pl.cap_vlong_longest))) return OWNER_WG;
     if (!sparse && pl.nlong <= a.tun.wg_decode_max && a.tun.wg_decode_max != 0) {
         const uint64_t ssz = a.slots.size(s);
-        if (strays_early<FMT>(a.words + a.slots.begin(s), nw < ssz ? nw : ssz)) return OWNER_WG;
+        if (workgroup_suits_early<FMT>(a.words + a.slots.begin(s), nw < ssz ? nw : ssz)) return OWNER_WG;
     }
     const bool dense_batch = pl.words_long * 64 > pl.cap_long * a.tun.dense_bits;
     return pl.nlong <= (dense_batch ? a.tun.wave_decode_max_dense : a.tun.wave_decode_max) ? OWNER_WAVE : OWNER_LANE;
