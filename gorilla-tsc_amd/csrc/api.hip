@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -114,7 +115,7 @@ struct gtsc_ctx {
     DeviceBuf dfcm_tables[1 + NSTAGE];  // device entry points, then one per stage of the host pipeline
     // staging for the host entry points
     hipStream_t copy_in = nullptr, work = nullptr, copy_out = nullptr, work2 = nullptr;
-    hipEvent_t dev_planned = nullptr, dev_joined = nullptr;   // the device entry point's fork onto work2 (see DecodeFork)
+    bool holds_priority_pair = false;   // copy_in and copy_out were made with the highest stream priority
     struct Stage {
         // the chunk's input has arrived / its kernels are done / its results have left the stage's buffers
         hipEvent_t copied_in = nullptr, coded = nullptr, drained = nullptr, planned = nullptr, joined = nullptr;
@@ -124,6 +125,8 @@ struct gtsc_ctx {
 };
 
 namespace {
+
+void release_priority_pair(int device);
 
 struct DeviceGuard {
     int prev = -1;
@@ -268,7 +271,7 @@ int gtsc_destroy(gtsc_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t q : {c->copy_in, c->work, c->copy_out, c->work2})
         if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-    for (hipEvent_t e : {c->dev_planned, c->dev_joined}) if (e) (void)hipEventDestroy(e);
+    if (c->holds_priority_pair) release_priority_pair(c->device);
     for (auto& s : c->stage) {
         for (hipEvent_t e : {s.copied_in, s.coded, s.drained, s.planned, s.joined}) if (e) (void)hipEventDestroy(e);
         s.h_off_a.release(); s.h_off_b.release();
@@ -449,15 +452,10 @@ int gtsc_decode_device(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t
     c->last_dispatch = 0;
     DecodeArgs a{nseries, words, Layout{in_off, uniform_slot_words}, in_nwords, ts, val, Layout{pt_off, uniform_capacity},
                  out_npoints, status, c->d_flags, tables, c->dfcm_mask, 0u, ~0ull, nullptr, c->d_plans, 0u, 0u, c->tun, &c->last_dispatch};
-    // a ragged batch may have blocks for all three decompressors: the workgroup one runs beside the other two
-    DecodeFork fork{};
-    if (pt_off) {
-        if (!c->work2) HIP_TRY(hipStreamCreateWithFlags(&c->work2, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&c->dev_planned, &c->dev_joined})
-            if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        fork = DecodeFork{c->work2, c->dev_planned, c->dev_joined};
-    }
-    HIP_TRY(launch_decode(a, format, c->stream, pt_off ? &fork : nullptr));
+    // (No second stream here, unlike the host pipeline: a caller's blocking copy on this stream right after the call
+    // -- hipMemcpy into pageable memory -- would wait inside the runtime for kernels on two streams, and that wait has
+    // been seen not to return.)
+    HIP_TRY(launch_decode(a, format, c->stream));
     return GTSC_OK;
 }
 
@@ -583,6 +581,14 @@ std::vector<Chunk> plan_chunks(uint64_t nseries, const uint64_t* off, uint64_t u
     return out;
 }
 
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> priority_pairs[MAX_DEVICES];   // contexts per device whose copy streams have the highest priority
+
+void release_priority_pair(int device)
+{
+    if (device >= 0 && device < MAX_DEVICES) priority_pairs[device].fetch_sub(1);
+}
+
 int ensure_stage_streams(gtsc_ctx* c)
 {
     // The runtime hands streams of one priority a small pool of hardware queues (four by default), and streams that
@@ -590,10 +596,18 @@ int ensure_stage_streams(gtsc_ctx* c)
     // the highest priority: that is a pool of their own, and what they move is what everything else waits for.
     // (Two and no more: with a third stream of that priority in the process, calls of many chunks stalled for
     // tens of seconds on the box this was measured on.)
-    int least = 0, greatest = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    for (hipStream_t* q : {&c->copy_in, &c->copy_out})
-        if (!*q) HIP_TRY(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
+    // One context per device holds such a pair; the copy streams of further contexts on the same device are ordinary
+    // streams (they may share queues with others and run slower, but they cannot stall).
+    if (!c->copy_in && !c->copy_out) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int dev = c->device >= 0 && c->device < MAX_DEVICES ? c->device : -1;
+        const bool first = dev >= 0 && priority_pairs[dev].fetch_add(1) == 0;
+        if (dev >= 0 && !first) priority_pairs[dev].fetch_sub(1);
+        c->holds_priority_pair = first;
+        for (hipStream_t* q : {&c->copy_in, &c->copy_out})
+            HIP_TRY(hipStreamCreateWithPriority(q, hipStreamNonBlocking, first ? greatest : 0));
+    }
     for (hipStream_t* q : {&c->work, &c->work2})
         if (!*q) HIP_TRY(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
     for (auto& st : c->stage)
@@ -621,6 +635,19 @@ bool injected_failure(size_t chunk)
 {
     static const long k = [] { const char* e = getenv("GTSC_TEST_FAIL_CHUNK"); return e && *e ? strtol(e, nullptr, 10) : -1L; }();
     return k >= 0 && (size_t)k == chunk;
+}
+
+// Whether p is page-locked (or registered) host memory: copies to and from such memory are asynchronous; with
+// pageable memory hipMemcpyAsync blocks the calling thread until the copy is done.
+bool page_locked(const void* p)
+{
+    if (!p) return true;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();   // (not an error of the call's: the pointer is simply not the runtime's)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
 }
 
 // status bits raised by the host pipeline (its streams are idle when this is called)
@@ -776,6 +803,12 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
     PipelineDrain drain{c};
 
     const std::vector<Chunk> chunks = plan_chunks(nseries, pt_off, uniform_capacity, false);
+    // Copies into pageable memory block this thread inside hipMemcpyAsync, behind everything their stream waits
+    // for -- here the chunk's kernels on two other streams.  That wait has been seen never to return (about one
+    // run of the test suite in three, always at the first copy out of a chunk whose workgroup-per-block kernel ran
+    // on the second work stream), while a hipStreamSynchronize of the work streams in the same place always does:
+    // with pageable output the work streams are synchronised before the copies are made.
+    const bool blocking_out = !(page_locked(ts) && page_locked(val) && page_locked(out_npoints) && page_locked(status));
     bool used[NSTAGE] = {};
     for (size_t k = 0; k < chunks.size(); k++) {
         const int b = (int)(k % NSTAGE);
@@ -820,6 +853,10 @@ int gtsc_decode_host(gtsc_ctx* c, int format, uint64_t nseries, const uint64_t* 
         const DecodeFork fork{c->work2, st.planned, st.joined};
         HIP_TRY(launch_decode(a, format, work, &fork));
         HIP_TRY(hipEventRecord(st.coded, work));
+        if (blocking_out) {
+            HIP_TRY(hipStreamSynchronize(c->work2));
+            HIP_TRY(hipStreamSynchronize(work));
+        }
         HIP_TRY(hipStreamWaitEvent(c->copy_out, st.coded, 0));
         if (np) {
             HIP_TRY(hipMemcpyAsync(ts + p0, st.ts.p, np * 8, hipMemcpyDeviceToHost, c->copy_out));

@@ -1538,6 +1538,7 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream, c
                 if (hipError_t e = hipStreamWaitEvent(fork->side, fork->planned, 0)) return e;
                 if (hipError_t e = launch_decode_blocks_wg(a, format, fork->side)) return e;
                 if (hipError_t e = hipEventRecord(fork->joined, fork->side)) return e;
+                (void)hipStreamQuery(fork->side);   // (hands the side stream's commands to the device now: nothing else will ask for them)
                 joined = false;
             } else if (hipError_t e = launch_decode_blocks_wg(a, format, stream)) return e;
         }
