@@ -1543,8 +1543,9 @@ hipError_t launch_decode(const DecodeArgs& a0, int format, hipStream_t stream, c
             } else if (hipError_t e = launch_decode_blocks_wg(a, format, stream)) return e;
         }
         if (wave_possible) if (hipError_t e = launch_decode_blocks(a, format, stream)) return e;
-        if (!a.pts.off && a.tun.long_points == 0 && a.tun.wave_decode_max >= a.nseries && a.tun.wave_decode_max_dense >= a.nseries) {
-            // every block is "long" and a wave or workgroup takes it whatever the plan says: nothing is left for the lanes
+        if (!a.pts.off && a.tun.wave_decode_max >= a.nseries && a.tun.wave_decode_max_dense >= a.nseries) {
+            // a uniform batch of long blocks, few enough for a wave or a workgroup each whatever the plan says: nothing is
+            // left for the lanes
             if (!joined) if (hipError_t e = hipStreamWaitEvent(stream, fork->joined, 0)) return e;
             return hipGetLastError();
         }
